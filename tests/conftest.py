@@ -1,0 +1,63 @@
+"""pytest configuration: markers, paths, golden-vector loading, parity metric."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, GOLDEN):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def parity(y, ref, floor=0.0):
+    """E_norm = max|y-ref| / max|ref|, and the pointwise relative error
+    restricted to |ref| >= 1e-3 max|ref|.  Returns (e_norm, e_point).  `floor` is a lower
+    bound for the scale (used when the exact answer is identically zero, e.g. a mixed
+    derivative of a separable sum, where max|ref| is itself rounding noise)."""
+    y = np.asarray(y, dtype=float)
+    ref = np.asarray(ref, dtype=float)
+    assert y.shape == ref.shape
+    scale = max(float(np.max(np.abs(ref))), float(floor))
+    if scale == 0:
+        return float(np.max(np.abs(y))), 0.0
+    e_norm = float(np.max(np.abs(y - ref)) / scale)
+    big = np.abs(ref) >= 1e-3 * scale
+    e_point = float(np.max(np.abs(y[big] - ref[big]) / np.abs(ref[big]))) if big.any() else 0.0
+    return e_norm, e_point
+
+
+def assert_parity(y, ref, tol=1e-12, what="", point_tol=None, floor=0.0):
+    """Normwise bound `tol` (the north_star's 1e-12 for fp64 barycentric) plus a pointwise
+    bound on the significant points.  For derivative specs pass point_tol=1e-11: two valid
+    fp64 summation orders of a D^2-transformed tensor already differ by ~2e-12 pointwise
+    (SURVEY.md App. B), so only the normwise figure can be held at 1e-12 there."""
+    e_norm, e_point = parity(y, ref, floor)
+    point_tol = tol if point_tol is None else point_tol
+    assert e_norm <= tol and e_point <= point_tol, \
+        f"{what}: E_norm={e_norm:.3e} (tol {tol}) E_point={e_point:.3e} (tol {point_tol})"
+
+
+def spec_point_tol(spec):
+    """Pointwise bound: 1e-12 for value specs.  Derivative specs are held to the normwise
+    1e-12 only: the differentiation matrices amplify rounding by ~n^2 per order, so two
+    equally valid fp64 evaluation orders (the reference's own dgemm vs dgemv siblings
+    included) differ pointwise by 1e-11..1e-10 at n = 12..20 while agreeing normwise."""
+    return 1e-12 if not any(int(v) for v in spec) else float("inf")
+
+
+@pytest.fixture(scope="session")
+def oracle_mod():
+    import oracle
+    oracle.build()
+    return oracle

@@ -1,0 +1,290 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the reference.
+
+Run in the build container only (the reference checkout does not travel to the GPU box):
+
+    python tests/golden/generate_golden.py [--ref /root/reference]
+
+It imports PyChebyshev v0.21.1 from ``<ref>/src``, feeds it seeded inputs and stores
+inputs + the reference's outputs as compressed ``.npz`` files.  Nothing of the
+reference's source is stored -- only arrays.  The two ``.pcb`` files copied from the
+reference's ``tests/fixtures`` are data files its own tests hold.
+
+Sets:
+  g1_sincos2d      config 1: 2-D sin*cos, 12x12, 10^4 points, 5 derivative specs
+  g2_bs5d          configs 2/4: 5-D Black-Scholes 11^5, value + Greeks (batch and multi)
+  g3_pcb           the reference's own .pcb fixtures evaluated at seeded points
+  g4_tt_bs5d       config 3: TT-Cross 5-D BS (max_rank 8 and 15, seed 42), eval + FD Greeks
+  g5_tt_rank16     config 5: synthetic rank-16 10-D cores, eval_batch (+ permuted dim order)
+  g6_primitives    nodes / weights / diff matrices / maxvol / value->coeff transform
+  g7_tt_small      TT-Cross on 3-D sin-sum and 10-D sin-sum (ranks, evals, values)
+  g8_small_bary    small odd-shaped barycentric cases incl. exact-node and edge points
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import shutil
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import functions as F  # noqa: E402
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    args = ap.parse_args()
+    sys.path.insert(0, os.path.join(args.ref, "src"))
+    import pychebyshev as ref
+    from pychebyshev import ChebyshevApproximation, ChebyshevTT
+    from pychebyshev import tensor_train as ref_tt
+    from pychebyshev import barycentric as ref_b
+
+    print("reference version", ref.__version__)
+    t0 = time.time()
+
+    # ---------------------------------------------------------------- g1
+    cheb = ChebyshevApproximation(F.sin_cos_2d, 2, [[-1, 1], [-1, 1]], [12, 12])
+    cheb.build(verbose=False)
+    pts = np.random.default_rng(1).uniform(-1, 1, (10_000, 2))
+    specs = [[0, 0], [1, 0], [0, 1], [2, 0], [1, 1]]
+    outs = np.stack([cheb.vectorized_eval_batch(pts, s) for s in specs])
+    save("g1_sincos2d", tensor=cheb.tensor_values, nodes0=cheb.nodes[0], nodes1=cheb.nodes[1],
+         weights0=cheb.weights[0], weights1=cheb.weights[1], diff0=cheb.diff_matrices[0],
+         diff1=cheb.diff_matrices[1], specs=np.array(specs), out=outs, seed=np.array(1))
+
+    # ---------------------------------------------------------------- g2
+    info = ChebyshevApproximation.nodes(5, F.BS5_DOMAIN, F.BS5_NODES)
+    tensor = np.array([F.bs_5d(list(p)) for p in info["full_grid"]]).reshape(info["shape"])
+    bs = ChebyshevApproximation.from_values(tensor, 5, F.BS5_DOMAIN, F.BS5_NODES)
+    rng = np.random.default_rng(2024)
+    main_pts = F.bs5_query_points(4096, seed=99)
+    # deep-OTM corner (prices ~1e-6..1e-3) and domain-boundary points
+    lo = np.array([b[0] for b in F.BS5_DOMAIN])
+    hi = np.array([b[1] for b in F.BS5_DOMAIN])
+    corner = np.column_stack([
+        rng.uniform(80, 82, 128), rng.uniform(108, 110, 128), rng.uniform(0.25, 0.3, 128),
+        rng.uniform(0.15, 0.17, 128), rng.uniform(0.01, 0.08, 128)])
+    edge = lo + (hi - lo) * rng.integers(0, 2, (128, 5))
+    # exact-node points: every coordinate on a node, and mixed (some dims on a node)
+    idx = rng.integers(0, 11, (32, 5))
+    exact_all = np.column_stack([bs.nodes[d][idx[:, d]] for d in range(5)])
+    mixed = F.bs5_query_points(32, seed=7)
+    mask = rng.integers(0, 2, (32, 5)).astype(bool)
+    idx2 = rng.integers(0, 11, (32, 5))
+    for d in range(5):
+        mixed[mask[:, d], d] = bs.nodes[d][idx2[mask[:, d], d]]
+    # within 1e-14 of a node but not equal (exercises the < 1e-14 rule on dims with |x|<~1)
+    near = F.bs5_query_points(16, seed=8)
+    near[:, 2] = bs.nodes[2][rng.integers(0, 11, 16)] + 3e-15
+    near[:, 3] = bs.nodes[3][rng.integers(0, 11, 16)] - 4e-15
+    pts = np.vstack([main_pts, corner, edge, exact_all, mixed, near])
+    specs = F.GREEK_SPECS_5D
+    outs = np.stack([bs.vectorized_eval_batch(pts, s) for s in specs])
+    sub = np.r_[0:48, 4096:4104, 4352:4360, 4384:4400, 4416:4424]
+    multi = np.array([bs.vectorized_eval_multi(list(pts[i]), specs) for i in sub])
+    single = np.array([[bs.vectorized_eval(list(pts[i]), s) for s in specs] for i in sub[:16]])
+    scalar = np.array([[bs.eval(list(pts[i]), s) for s in specs[:3]] for i in sub[:4]])
+    save("g2_bs5d", tensor=tensor, points=pts, specs=np.array(specs), out=outs,
+         multi_idx=sub, multi=multi, single=single, scalar=scalar,
+         **{f"nodes{d}": bs.nodes[d] for d in range(5)},
+         **{f"weights{d}": bs.weights[d] for d in range(5)},
+         **{f"diff{d}": bs.diff_matrices[d] for d in range(5)})
+
+    # ---------------------------------------------------------------- g3
+    for name in ("approx_5d_bs.pcb", "approx_2d_simple.pcb"):
+        shutil.copyfile(os.path.join(args.ref, "tests", "fixtures", name), os.path.join(HERE, name))
+    a5 = ChebyshevApproximation.load(os.path.join(HERE, "approx_5d_bs.pcb"))
+    a2 = ChebyshevApproximation.load(os.path.join(HERE, "approx_2d_simple.pcb"))
+    p5 = np.random.default_rng(5).uniform(-1, 1, (1000, 5))
+    p2 = np.random.default_rng(6).uniform(-1, 1, (1000, 2))
+    save("g3_pcb", p5=p5, p2=p2,
+         v5=a5.vectorized_eval_batch(p5, [0] * 5), v2=a2.vectorized_eval_batch(p2, [0, 0]),
+         d5=a5.vectorized_eval_batch(p5, [0, 1, 0, 0, 1]), d2=a2.vectorized_eval_batch(p2, [1, 1]))
+
+    # ---------------------------------------------------------------- g4
+    g4 = {}
+    tt_pts = F.bs5_query_points(4096, seed=99)
+    scen = F.bs5_query_points(10, seed=123)
+    scen[0] = [80.0, 90.0, 0.25, 0.15, 0.01]          # domain corner: exercises the FD nudge
+    scen[1] = [120.0, 110.0, 1.0, 0.35, 0.08]
+    fd_specs = [[0, 0, 0, 0, 0], [1, 0, 0, 0, 0], [2, 0, 0, 0, 0], [0, 0, 0, 1, 0],
+                [1, 0, 0, 1, 0], [2, 0, 1, 0, 0], [1, 1, 1, 0, 0]]
+    for mr in (8, 15):
+        piv_log = []
+        orig = ref_tt._maxvol
+
+        def rec(A, *a, _orig=orig, **k):
+            out = _orig(A, *a, **k)
+            piv_log.append(np.array(out, dtype=np.int64))
+            return out
+        ref_tt._maxvol = rec
+        try:
+            tt = ChebyshevTT(F.bs_5d, 5, F.BS5_DOMAIN, F.BS5_NODES, max_rank=mr,
+                             max_sweeps=10 if mr == 8 else 5)
+            tt.build(verbose=False, seed=42)
+        finally:
+            ref_tt._maxvol = orig
+        g4[f"r{mr}_ranks"] = np.array(tt.tt_ranks)
+        g4[f"r{mr}_evals"] = np.array(tt.total_build_evals)
+        for k, c in enumerate(tt._coeff_cores):
+            g4[f"r{mr}_core{k}"] = c
+        g4[f"r{mr}_eval"] = tt.eval_batch(tt_pts)
+        g4[f"r{mr}_fd"] = np.array([tt.eval_multi(list(s), fd_specs) for s in scen])
+        g4[f"r{mr}_npiv"] = np.array(len(piv_log))
+        g4[f"r{mr}_pivots"] = np.concatenate(piv_log)
+        g4[f"r{mr}_pivlens"] = np.array([len(p) for p in piv_log])
+        print(f"  TT-Cross max_rank={mr}: ranks {tt.tt_ranks}, evals {tt.total_build_evals}")
+    save("g4_tt_bs5d", points=tt_pts, scenarios=scen, fd_specs=np.array(fd_specs), **g4)
+
+    # ---------------------------------------------------------------- g5
+    d, n, r = 10, 11, 16
+    ranks = [1] + [r] * (d - 1) + [1]
+    rng = np.random.default_rng(16)
+    cores = [rng.standard_normal((ranks[k], n, ranks[k + 1])) / np.sqrt(ranks[k] * n)
+             for k in range(d)]
+    dom = [[-1.0, 1.0]] * d
+
+    def make_tt(cores, dom, order=None):
+        obj = ChebyshevTT.__new__(ChebyshevTT)
+        obj.function = None
+        obj.num_dimensions = len(cores)
+        obj.domain = [list(b) for b in dom]
+        obj.n_nodes = [c.shape[1] for c in cores]
+        obj.max_rank = max(c.shape[2] for c in cores)
+        obj.tolerance = 1e-6
+        obj.max_sweeps = 10
+        obj.max_derivative_order = 2
+        obj.additional_data = None
+        obj.descriptor = ""
+        obj.method = "cross"
+        obj._coeff_cores = [np.array(c) for c in cores]
+        obj._tt_ranks = [1] + [c.shape[2] for c in cores]
+        obj._built = True
+        obj._build_time = 0.0
+        obj._total_build_evals = 0
+        obj._cached_error_estimate = None
+        obj._dim_order = list(order) if order is not None else list(range(len(cores)))
+        return obj
+
+    p10 = np.random.default_rng(99).uniform(-1, 1, (4096, d))
+    perm = [3, 0, 7, 1, 9, 2, 8, 4, 6, 5]
+    save("g5_tt_rank16", points=p10, perm=np.array(perm),
+         out=make_tt(cores, dom).eval_batch(p10),
+         out_perm=make_tt(cores, dom, perm).eval_batch(p10),
+         single=np.array([make_tt(cores, dom, perm).eval(list(p)) for p in p10[:8]]),
+         **{f"core{k}": c for k, c in enumerate(cores)})
+
+    # mixed-rank / mixed-n / non-unit-domain TT
+    rk = [1, 3, 5, 2, 1]
+    nn = [4, 7, 3, 9]
+    rng = np.random.default_rng(17)
+    cores_m = [rng.standard_normal((rk[k], nn[k], rk[k + 1])) for k in range(4)]
+    dom_m = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
+    pm = np.column_stack([np.random.default_rng(18).uniform(lo_, hi_, 512) for lo_, hi_ in dom_m])
+    save("g5b_tt_mixed", points=pm, ranks=np.array(rk), out=make_tt(cores_m, dom_m).eval_batch(pm),
+         **{f"core{k}": c for k, c in enumerate(cores_m)})
+
+    # ---------------------------------------------------------------- g6
+    g6 = {}
+    for n_ in list(range(2, 17)) + [32, 64]:
+        for tag, (a, b) in (("u", (-1.0, 1.0)), ("s", (80.0, 120.0))):
+            x = ChebyshevApproximation.nodes(1, [[a, b]], [n_])["nodes_per_dim"][0]
+            w = ref_b.compute_barycentric_weights(x)
+            g6[f"x_{tag}{n_}"] = x
+            g6[f"w_{tag}{n_}"] = w
+            g6[f"D_{tag}{n_}"] = ref_b.compute_differentiation_matrix(x, w)
+    rng = np.random.default_rng(33)
+    mats, pivs = [], []
+    for t in range(20):
+        m_, r_ = (88, 8) if t < 12 else (176, 16) if t < 16 else (33, 3)
+        A = np.linalg.qr(rng.standard_normal((m_, r_)))[0]
+        g6[f"mv_A{t}"] = A
+        g6[f"mv_p{t}"] = np.array(ref_tt._maxvol(A), dtype=np.int64)
+    vc = rng.standard_normal((4, 11, 6))
+    g6["vc"] = vc
+    g6["cc"] = ref_tt._value_core_to_coeff_core(vc)
+    vc2 = rng.standard_normal((1, 5, 3))
+    g6["vc2"] = vc2
+    g6["cc2"] = ref_tt._value_core_to_coeff_core(vc2)
+    save("g6_primitives", **g6)
+
+    # ---------------------------------------------------------------- g7
+    g7 = {}
+    tt3 = ChebyshevTT(F.sin_sum_3d, 3, [[-1, 1]] * 3, [11, 11, 11], max_rank=5)
+    tt3.build(verbose=False, seed=42)
+    p3 = np.random.default_rng(3).uniform(-1, 1, (256, 3))
+    g7.update(s3_ranks=np.array(tt3.tt_ranks), s3_evals=np.array(tt3.total_build_evals),
+              s3_points=p3, s3_eval=tt3.eval_batch(p3))
+    tt10 = ChebyshevTT(F.sin_sum_nd, 10, [[-1, 1]] * 10, [11] * 10, max_rank=16)
+    tt10.build(verbose=False, seed=42)
+    p10b = np.random.default_rng(4).uniform(-1, 1, (256, 10))
+    g7.update(s10_ranks=np.array(tt10.tt_ranks), s10_evals=np.array(tt10.total_build_evals),
+              s10_points=p10b, s10_eval=tt10.eval_batch(p10b))
+    # a non-converging case (max_sweeps exhausted -> best cores), different seed, rank cap 4
+    ttx = ChebyshevTT(F.bs_5d, 5, F.BS5_DOMAIN, [7, 6, 5, 6, 4], max_rank=4, max_sweeps=3)
+    ttx.build(verbose=False, seed=7)
+    px = np.column_stack([np.random.default_rng(9).uniform(lo_, hi_, 256) for lo_, hi_ in F.BS5_DOMAIN])
+    g7.update(x_ranks=np.array(ttx.tt_ranks), x_evals=np.array(ttx.total_build_evals),
+              x_points=px, x_eval=ttx.eval_batch(px))
+    print(f"  3-D sin: {tt3.tt_ranks} {tt3.total_build_evals}; 10-D sin: {tt10.tt_ranks} "
+          f"{tt10.total_build_evals}; capped BS: {ttx.tt_ranks} {ttx.total_build_evals}")
+    save("g7_tt_small", **g7)
+
+    # ---------------------------------------------------------------- g8
+    g8 = {}
+    cases = {
+        "a": (1, [[0.0, 3.15]], [20], lambda x, _: np.sin(x[0])),
+        "b": (3, [[-1, 1], [-1, 1], [1, 3]], [10, 8, 4], F.sin_sum_3d),
+        "c": (3, [[50, 150], [0.1, 2.0], [0.1, 0.5]], [15, 12, 10], F.bs_3d),
+        "d": (4, [[-2, 2], [0, 1], [-1, 0], [3, 5]], [3, 5, 2, 7],
+              lambda x, _: x[0] * x[1] - x[2] ** 2 + np.cos(x[3])),
+        "e": (2, [[-1, 1], [-1, 1]], [1, 6], lambda x, _: 2.0 + x[1] ** 3),
+    }
+    for tag, (dd, dom_, nn_, fn) in cases.items():
+        c = ChebyshevApproximation(fn, dd, dom_, nn_)
+        c.build(verbose=False)
+        rngc = np.random.default_rng(100 + ord(tag))
+        pts_ = np.column_stack([rngc.uniform(lo_, hi_, 200) for lo_, hi_ in dom_])
+        # rows 0..9: exactly on nodes; rows 10..14: outside the domain (extrapolation)
+        for i in range(10):
+            for k in range(dd):
+                pts_[i, k] = c.nodes[k][rngc.integers(0, nn_[k])]
+        for i in range(10, 15):
+            pts_[i] = [lo_ - 0.1 * (hi_ - lo_) if (i + k) % 2 else hi_ + 0.05 * (hi_ - lo_)
+                       for k, (lo_, hi_) in enumerate(dom_)]
+        specs_ = [[0] * dd]
+        if all(v > 2 for v in nn_):
+            s1 = [0] * dd
+            s1[0] = 1
+            s2 = [0] * dd
+            s2[-1] = 2
+            specs_ += [s1, s2]
+            if dd > 1:
+                s3 = [0] * dd
+                s3[0] = 1
+                s3[-1] = 1
+                specs_.append(s3)
+        g8[f"{tag}_tensor"] = c.tensor_values
+        g8[f"{tag}_domain"] = np.array(dom_, dtype=float)
+        g8[f"{tag}_points"] = pts_
+        g8[f"{tag}_specs"] = np.array(specs_)
+        g8[f"{tag}_out"] = np.stack([c.vectorized_eval_batch(pts_, s) for s in specs_])
+    save("g8_small_bary", **g8)
+
+    print(f"done in {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main()
