@@ -1,0 +1,143 @@
+/*
+ * pcx.h -- C ABI of libpcx_hip.so: MI355X (gfx950) batched evaluation of Chebyshev
+ * interpolants, the drop-in for PyChebyshev's evaluation hot path.
+ *
+ * The reference (PyChebyshev v0.21.1) is pure Python/NumPy and has NO FFI seam; the
+ * seam is its Python class surface.  Each entry point below therefore names the
+ * reference *method* (file:line under /root/reference/src/pychebyshev/) whose work it
+ * replaces.  The Python classes in pychebyshev_amd/ are the only intended callers;
+ * INTEGRATION.md shows the ctypes binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
+ *   - return 0 (PCX_OK) or a negative PCX_ERR_* code; never throws.  pcx_last_error()
+ *     returns a thread-local description of the last failure on the calling thread.
+ *   - all floating point is IEEE float64; tensors are C-order (last index fastest);
+ *     `pts` is an (N, d) row-major array, exactly the ndarray the reference takes.
+ *   - the library copies model data at create; callers keep ownership of every buffer
+ *     they pass.  Handles are immutable after create except for an internal cache of
+ *     derivative-transformed tensors (mutex-protected); one handle may be used from
+ *     several host threads.
+ *   - one handle lives on ONE device (one process per GPU; shard batches across
+ *     processes/handles -- the path has no cross-device exchange).
+ *   - "_dev" variants take DEVICE pointers and only enqueue work on the given HIP
+ *     stream (NULL = the handle's own stream); they do not synchronize.
+ */
+#ifndef PCX_H
+#define PCX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PCX_ABI_VERSION 1
+
+#define PCX_OK 0
+#define PCX_ERR_INVALID (-1)     /* bad argument (shape, NULL, range)               */
+#define PCX_ERR_NO_DEVICE (-2)   /* no usable HIP device / device index out of range */
+#define PCX_ERR_HIP (-3)         /* a HIP runtime call failed                        */
+#define PCX_ERR_UNSUPPORTED (-4) /* valid request outside what the kernels cover     */
+#define PCX_ERR_NOMEM (-5)
+
+#define PCX_MAX_DIMS 16
+
+typedef struct pcx_bary pcx_bary; /* device-resident ChebyshevApproximation state */
+typedef struct pcx_tt pcx_tt;     /* device-resident ChebyshevTT coefficient cores */
+
+/* ---- library / device ------------------------------------------------------ */
+int pcx_abi_version(void);
+const char *pcx_last_error(void);
+int pcx_device_count(int *n);
+int pcx_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+
+/* Device-memory plumbing for callers that keep query batches resident in HBM
+ * (bench.py, multi-GPU drivers).  `stream` arguments are hipStream_t passed as void*. */
+int pcx_dev_malloc(int device, size_t bytes, void **dptr);
+int pcx_dev_free(int device, void *dptr);
+int pcx_memcpy_h2d(int device, void *dst, const void *src, size_t bytes);
+int pcx_memcpy_d2h(int device, void *dst, const void *src, size_t bytes);
+int pcx_device_synchronize(int device);
+int pcx_event_create(int device, void **event);
+int pcx_event_record(void *event, void *stream);
+int pcx_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronizes on `stop` */
+int pcx_event_destroy(void *event);
+
+/* ---- barycentric full-tensor interpolant ----------------------------------- */
+/* State of ChebyshevApproximation (barycentric.py:401-414): per-dimension nodes,
+ * barycentric weights and differentiation matrices (concatenated: sum n_d, sum n_d,
+ * sum n_d^2 doubles, each D_d row-major) and tensor_values (prod n_d doubles, C-order).
+ * Built by the host exactly as barycentric.py:440-452, :30-49, :52-77 do.            */
+int pcx_bary_create(int device, int d, const int32_t *n_nodes, const double *nodes_cat,
+                    const double *weights_cat, const double *diffmat_cat, const double *tensor,
+                    pcx_bary **out);
+int pcx_bary_destroy(pcx_bary *h);
+
+/* vectorized_eval_batch (barycentric.py:992-1047): _apply_derivative_passes
+ * (:951-990) once for `deriv` (d orders, NULL = all zero; cached per handle), then per
+ * point the exact-node test |x - node| < 1e-14 / (T . w/diff) / sum(w/diff) reduction
+ * over all dimensions.  Host-pointer form: copies pts in, result out, synchronizes.   */
+int pcx_bary_eval_batch(pcx_bary *h, const double *pts, int64_t N, const int32_t *deriv,
+                        double *out);
+int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t N, const int32_t *deriv,
+                            double *d_out, void *stream);
+
+/* vectorized_eval_multi (barycentric.py:1049-1112) batched over points: m derivative
+ * specs (m x d orders) at each of N points; out is (N, m) row-major.                  */
+int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs,
+                              int m, double *out);
+
+/* The derivative-transformed tensor of _apply_derivative_passes (:951-990), copied to
+ * the host (prod n_d doubles) -- lets tests check kernel K3 on its own.               */
+int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, double *tensor_out);
+
+/* Kernel selection and introspection.  variant: 0 = auto, 1 = row-parallel VALU kernel
+ * (any shape), 2 = MFMA kernel (v_mfma_f64_16x16x4_f64).  info_out receives
+ * {variant used by auto, row tiles, k-steps, lds bytes, points per workgroup, split}.  */
+int pcx_bary_set_kernel(pcx_bary *h, int variant);
+int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
+int pcx_bary_stream(pcx_bary *h, void **stream);
+
+/* ---- tensor-train interpolant ---------------------------------------------- */
+/* State of ChebyshevTT (tensor_train.py:1117-1138): Chebyshev COEFFICIENT cores
+ * (r_{k-1}, n_k, r_k) C-order concatenated, ranks (d+1, ranks[0]=ranks[d]=1), domain,
+ * and dim_order (storage position k reads user column dim_order[k]; NULL = identity). */
+int pcx_tt_create(int device, int d, const int32_t *n_nodes, const int32_t *ranks,
+                  const double *lo, const double *hi, const double *coeff_cores_cat,
+                  const int32_t *dim_order, pcx_tt **out);
+int pcx_tt_destroy(pcx_tt *h);
+
+/* eval_batch (tensor_train.py:2217-2265): per storage dim scale to [-1,1], Chebyshev
+ * polynomials T_0..T_{n-1}, contract with the core, chain-multiply.                   */
+int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double *out);
+int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, double *d_out, void *stream);
+int pcx_tt_stream(pcx_tt *h, void **stream);
+
+/* ---- TT-Cross build steps (tensor_train.py:123-540) ------------------------- */
+/* One unfolding step of _tt_cross (:332-362 and :449-474): thin SVD of the m x c cross
+ * matrix C (row-major), rank = max(1, min(cap, #{S > rel_thresh*S0}, min(m,c))), maxvol
+ * rows of U[:, :rank] when m > rank, C_hat = U inv(U[piv]).  Outputs: chat (m x rank
+ * row-major), pivots (rank), rank.  Runs on `device` (single-workgroup HIP kernels).  */
+int pcx_tt_cross_step(int device, const double *C, int m, int c, int cap, double rel_thresh,
+                      double *chat, int64_t *pivots, int32_t *rank_out);
+
+/* _maxvol (:38-120) on a row-major m x r matrix; idx_out receives r row indices.      */
+int pcx_maxvol(int device, const double *A, int m, int r, double tol, int max_iters,
+               int64_t *idx_out);
+
+/* _value_core_to_coeff_core (:997-1016): DCT-II along the node axis, /n, c_0 halved.  */
+int pcx_tt_value_to_coeff_core(int device, const double *value_core, int rl, int n, int rr,
+                               double *coeff_core);
+
+/* _eval_tt (:223-228) batched: TT value at `count` integer grid index tuples
+ * (count x d int32, row-major) through the chain of VALUE cores (same layout as
+ * coeff_cores_cat).  Used by the convergence check (:287-297).                        */
+int pcx_tt_grid_eval(int device, int d, const int32_t *n_nodes, const int32_t *ranks,
+                     const double *value_cores_cat, const int32_t *idx, int count, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PCX_H */

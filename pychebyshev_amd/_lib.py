@@ -1,0 +1,167 @@
+"""ctypes binding of libpcx_hip.so (include/pcx.h).  No PyTorch, no CPU fallback.
+
+``load()`` raises :class:`PcxLibraryError` when the library is missing or does not export
+the full ABI; ``check(rc)`` turns negative return codes into Python exceptions carrying
+``pcx_last_error()``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libpcx_hip.so")
+
+PCX_OK = 0
+PCX_ERR_INVALID = -1
+PCX_ERR_NO_DEVICE = -2
+PCX_ERR_HIP = -3
+PCX_ERR_UNSUPPORTED = -4
+PCX_ERR_NOMEM = -5
+
+
+class PcxLibraryError(RuntimeError):
+    """libpcx_hip.so is missing, stale, or there is no usable MI355X device."""
+
+
+class PcxError(RuntimeError):
+    """A libpcx_hip call failed."""
+
+    def __init__(self, code: int, message: str):
+        super().__init__(f"libpcx_hip error {code}: {message}")
+        self.code = code
+
+
+c_i32p = ctypes.POINTER(ctypes.c_int32)
+c_i64p = ctypes.POINTER(ctypes.c_int64)
+c_f64p = ctypes.POINTER(ctypes.c_double)
+c_vpp = ctypes.POINTER(ctypes.c_void_p)
+_V = ctypes.c_void_p
+_I = ctypes.c_int
+_L = ctypes.c_int64
+_D = ctypes.c_double
+_Z = ctypes.c_size_t
+
+# name -> (restype, argtypes); mirrors include/pcx.h one-to-one
+SIGNATURES = {
+    "pcx_abi_version": (_I, []),
+    "pcx_last_error": (ctypes.c_char_p, []),
+    "pcx_device_count": (_I, [ctypes.POINTER(_I)]),
+    "pcx_device_info": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(_I), c_i64p]),
+    "pcx_dev_malloc": (_I, [_I, _Z, c_vpp]),
+    "pcx_dev_free": (_I, [_I, _V]),
+    "pcx_memcpy_h2d": (_I, [_I, _V, _V, _Z]),
+    "pcx_memcpy_d2h": (_I, [_I, _V, _V, _Z]),
+    "pcx_device_synchronize": (_I, [_I]),
+    "pcx_event_create": (_I, [_I, c_vpp]),
+    "pcx_event_record": (_I, [_V, _V]),
+    "pcx_event_elapsed_ms": (_I, [_V, _V, ctypes.POINTER(ctypes.c_float)]),
+    "pcx_event_destroy": (_I, [_V]),
+    "pcx_bary_create": (_I, [_I, _I, c_i32p, c_f64p, c_f64p, c_f64p, c_f64p, c_vpp]),
+    "pcx_bary_destroy": (_I, [_V]),
+    "pcx_bary_eval_batch": (_I, [_V, c_f64p, _L, c_i32p, c_f64p]),
+    "pcx_bary_eval_batch_dev": (_I, [_V, _V, _L, c_i32p, _V, _V]),
+    "pcx_bary_eval_multi_batch": (_I, [_V, c_f64p, _L, c_i32p, _I, c_f64p]),
+    "pcx_bary_derivative_tensor": (_I, [_V, c_i32p, c_f64p]),
+    "pcx_bary_set_kernel": (_I, [_V, _I]),
+    "pcx_bary_kernel_info": (_I, [_V, c_i32p]),
+    "pcx_bary_stream": (_I, [_V, c_vpp]),
+    "pcx_tt_create": (_I, [_I, _I, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p, c_i32p, c_vpp]),
+    "pcx_tt_destroy": (_I, [_V]),
+    "pcx_tt_eval_batch": (_I, [_V, c_f64p, _L, c_f64p]),
+    "pcx_tt_eval_batch_dev": (_I, [_V, _V, _L, _V, _V]),
+    "pcx_tt_stream": (_I, [_V, c_vpp]),
+    "pcx_tt_cross_step": (_I, [_I, c_f64p, _I, _I, _I, _D, c_f64p, c_i64p, c_i32p]),
+    "pcx_maxvol": (_I, [_I, c_f64p, _I, _I, _D, _I, c_i64p]),
+    "pcx_tt_value_to_coeff_core": (_I, [_I, c_f64p, _I, _I, _I, c_f64p]),
+    "pcx_tt_grid_eval": (_I, [_I, _I, c_i32p, c_i32p, c_f64p, c_i32p, _I, c_f64p]),
+}
+
+_LIB = None
+
+
+def load(path: str | None = None):
+    """Load libpcx_hip.so and bind every symbol of the ABI (raises if any is missing)."""
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    p = path or os.environ.get("PCX_HIP_LIBRARY") or LIB_PATH
+    if not os.path.exists(p):
+        raise PcxLibraryError(
+            f"{p} not found: build it with `python -m pychebyshev_amd._build` "
+            "(hipcc, --offload-arch=gfx950).  There is no CPU fallback.")
+    try:
+        lib = ctypes.CDLL(p)
+    except OSError as exc:
+        raise PcxLibraryError(f"cannot load {p}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise PcxLibraryError(f"{p} does not export {name}; rebuild it") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.pcx_abi_version() != 1:
+        raise PcxLibraryError(f"{p}: ABI version {lib.pcx_abi_version()} != 1")
+    if path is None:
+        _LIB = lib
+    return lib
+
+
+def last_error(lib=None) -> str:
+    lib = lib or load()
+    msg = lib.pcx_last_error()
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(rc: int, lib=None) -> None:
+    if rc == PCX_OK:
+        return
+    msg = last_error(lib)
+    if rc == PCX_ERR_NO_DEVICE:
+        raise PcxLibraryError(f"no usable HIP device: {msg}")
+    if rc == PCX_ERR_INVALID:
+        raise ValueError(f"libpcx_hip: {msg}")
+    if rc == PCX_ERR_UNSUPPORTED:
+        raise NotImplementedError(f"libpcx_hip: {msg}")
+    if rc == PCX_ERR_NOMEM:
+        raise MemoryError(f"libpcx_hip: {msg}")
+    raise PcxError(rc, msg)
+
+
+def device_count() -> int:
+    lib = load()
+    n = _I(0)
+    rc = lib.pcx_device_count(ctypes.byref(n))
+    return int(n.value) if rc == PCX_OK else 0
+
+
+def default_device() -> int:
+    """Device index for this process: PCX_DEVICE, else LOCAL_RANK (one process per GPU)."""
+    for key in ("PCX_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(key)
+        if v is not None and v.strip() != "":
+            return int(v)
+    return 0
+
+
+def f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def p_f64(a: np.ndarray):
+    return a.ctypes.data_as(c_f64p)
+
+
+def p_i32(a: np.ndarray):
+    return a.ctypes.data_as(c_i32p)
+
+
+def p_i64(a: np.ndarray):
+    return a.ctypes.data_as(c_i64p)

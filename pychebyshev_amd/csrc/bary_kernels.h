@@ -1,0 +1,236 @@
+// bary_kernels.h -- HIP kernels for the full-tensor barycentric interpolant (gfx950).
+//
+// Replaces the per-point NumPy loop of ChebyshevApproximation.vectorized_eval_batch
+// (reference barycentric.py:1035-1046) and _apply_derivative_passes (:951-990).
+//
+//   k_mode_product    K3: T' = T x_axis D  (one fma chain per output, j ascending --
+//                         the order OpenBLAS dgemm uses for the reference's arr @ D.T)
+//   k_pack_fragments  re-lays the (M x K) view of T' out in MFMA A-fragment order
+//   k_bary_mfma       K1+K2 fused: barycentric weights per point, then the dense
+//                         contraction as a (M x K) . (K x points) GEMM on
+//                         v_mfma_f64_16x16x4_f64 plus a VALU epilogue over the head dims
+//   k_bary_rows       K1+K2 for any shape: LPP lanes per point walk the tensor rows
+#pragma once
+
+#include "pcx_common.h"
+
+// ---------------------------------------------------------------------------------
+// K3: one pass of _apply_derivative_passes: out[o,i,q] = sum_j in[o,j,q] * D[i,j].
+// ---------------------------------------------------------------------------------
+__global__ void k_mode_product(const double *__restrict__ in, double *__restrict__ out,
+                               const double *__restrict__ D, long outer, int na, long inner) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = outer * na * inner;
+    if (idx >= total) return;
+    long q = idx % inner;
+    long t = idx / inner;
+    int i = (int)(t % na);
+    long o = t / na;
+    const double *src = in + (o * na) * inner + q;
+    const double *drow = D + (long)i * na;
+    double s = 0.0;
+    for (int j = 0; j < na; ++j) s = __builtin_fma(src[(long)j * inner], drow[j], s);
+    out[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------
+// A-fragment packing: frag[t][s][l] = T2[16 t + (l & 15)][4 s + (l >> 4)], zero padded,
+// where T2 is the C-order tensor viewed as (M x K).  One coalesced 512-byte read then
+// feeds one v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l & 15][l >> 4]).
+// ---------------------------------------------------------------------------------
+__global__ void k_pack_fragments(const double *__restrict__ T2, double *__restrict__ frag, int M,
+                                 int K, int MT, int KS) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    long total = (long)MT * KS * 64;
+    if (idx >= total) return;
+    int l = (int)(idx & 63);
+    long ts = idx >> 6;
+    int s = (int)(ts % KS);
+    int t = (int)(ts / KS);
+    int m = 16 * t + (l & 15);
+    int k = 4 * s + (l >> 4);
+    frag[idx] = (m < M && k < K) ? T2[(long)m * K + k] : 0.0;
+}
+
+// ---------------------------------------------------------------------------------
+// K1: normalised barycentric weights of one coordinate for one dimension
+// (reference barycentric.py:1039-1045 / :1083-1094): first node with |x - node| < 1e-14
+// gives a one-hot row, otherwise u_j = w_j / (x - node_j), b_j = u_j / sum(u).
+// Written to dst[j * stride].
+// ---------------------------------------------------------------------------------
+__device__ __forceinline__ void bary_weights_1d(double x, const double *__restrict__ nodes,
+                                                const double *__restrict__ wts, int n, double *dst,
+                                                int stride) {
+    int exact = -1;
+    for (int j = 0; j < n; ++j) {
+        double diff = x - nodes[j];
+        if (exact < 0 && __builtin_fabs(diff) < 1e-14) exact = j;
+    }
+    if (exact >= 0) {
+        for (int j = 0; j < n; ++j) dst[j * stride] = (j == exact) ? 1.0 : 0.0;
+    } else {
+        double su = 0.0;
+        for (int j = 0; j < n; ++j) {
+            double u = wts[j] / (x - nodes[j]);
+            dst[j * stride] = u;
+            su += u;
+        }
+        double r = 1.0 / su;
+        for (int j = 0; j < n; ++j) dst[j * stride] *= r;
+    }
+}
+
+__device__ __forceinline__ double code_weight(unsigned code, const double *bw_col, int PW) {
+    // product of the four table rows named by the 8-bit fields of `code`
+    double w0 = bw_col[(code & 255u) * PW];
+    double w1 = bw_col[((code >> 8) & 255u) * PW];
+    double w2 = bw_col[((code >> 16) & 255u) * PW];
+    double w3 = bw_col[(code >> 24) * PW];
+    return (w0 * w1) * (w2 * w3);
+}
+
+// ---------------------------------------------------------------------------------
+// K1+K2 fused, MFMA form.  One wave owns PW = 16*NT query points for the whole kernel.
+//
+//   prologue  weights of every dimension for the wave's points -> LDS table
+//             bw[row][point], rows = concatenated dims + one row of ones;
+//             B operands  B[nt][s] (lane l: k = 4s + (l>>4), point 16nt + (l&15))
+//             = product of the tail-dim weights named by kcode[k], kept in VGPRs.
+//   main      for each row tile t: acc[nt] = sum_s mfma(A = frag[t][s], B[nt][s]);
+//             D layout: lane l, reg j holds row (l>>4) + 4j, column (point) l & 15.
+//   epilogue  sum[nt] += acc[nt][j] * (product of head-dim weights named by
+//             rowcode[16t + (l>>4) + 4j]); finally add the four lane groups.
+//
+// 256 threads = 4 waves; dynamic LDS = 4 * (sum_n + 1) * PW * 8 bytes.
+// ---------------------------------------------------------------------------------
+template <int KS, int NT>
+__global__ void __launch_bounds__(256, 2)
+k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
+            const double *__restrict__ wts, const double *__restrict__ frag,
+            const unsigned *__restrict__ rowcode, const unsigned *__restrict__ kcode,
+            const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
+            long ooff) {
+    static_assert(NT == 1 || NT == 2 || NT == 4, "PW must divide the wave");
+    constexpr int PW = 16 * NT;
+    constexpr int PH = 64 / PW;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    const int c = lane & 15;
+    double *bw = lds + (size_t)wave * (dims.sum_n + 1) * PW;
+    const long base = ((long)blockIdx.x * 4 + wave) * PW;
+
+    // ---- prologue 1: barycentric weights (lane -> point lane % PW, dims strided by PH)
+    {
+        const int pp = lane % PW;
+        const int ph = lane / PW;
+        const long pidx = base + pp;
+        const bool valid = pidx < N;
+        for (int k = ph; k < dims.d; k += PH) {
+            const double *nd = nodes + dims.off[k];
+            double x = valid ? pts[pidx * dims.d + k] : nd[0];
+            bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + (size_t)dims.off[k] * PW + pp,
+                            PW);
+        }
+        if (ph == 0) bw[(size_t)dims.sum_n * PW + pp] = 1.0;
+    }
+    __syncthreads();
+
+    // ---- prologue 2: B operands in registers
+    double B[NT][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        unsigned code = kcode[4 * s + g];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bw + 16 * nt + c, PW);
+    }
+
+    // ---- main loop over row tiles
+    double sum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) sum[nt] = 0.0;
+    const double *tf = frag + lane;
+    for (int t = 0; t < plan.MT; ++t) {
+        double w[NT][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned code = rowcode[16 * t + g + 4 * j];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w[nt][j] = code_weight(code, bw + 16 * nt + c, PW);
+        }
+        pcx_d4 acc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
+        const double *tt = tf + (size_t)t * KS * 64;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            double a = tt[s * 64];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt][s], acc[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sum[nt] = __builtin_fma(acc[nt][j], w[nt][j], sum[nt]);
+    }
+
+    // ---- reduce the four 16-lane groups and store
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        double v = sum[nt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        long pidx = base + 16 * nt + c;
+        if (g == 0 && pidx < N) out[pidx * ostride + ooff] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------
+// K1+K2, row-parallel VALU form for any shape.  LPP (power of two <= 64) lanes share
+// one point: weights -> LDS, then lane r walks rows r, r+LPP, ... of the (M x K) view
+// with K = n[d-1], accumulating wM(row) * sum_k T[row,k] b_last[k]; shuffle-reduce.
+// dynamic LDS = (256 / LPP) * sum_n * 8 bytes.
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_bary_rows(BaryDims dims, int LPP, const double *__restrict__ nodes,
+            const double *__restrict__ wts, const double *__restrict__ T,
+            const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
+            long ooff) {
+    extern __shared__ double lds[];
+    const int ppw = 256 / LPP;                 // points per workgroup
+    const int pl = threadIdx.x / LPP;          // local point
+    const int sub = threadIdx.x % LPP;         // lane within the point's group
+    const long pidx = (long)blockIdx.x * ppw + pl;
+    const bool valid = pidx < N;
+    double *bw = lds + (size_t)pl * dims.sum_n;
+    for (int k = sub; k < dims.d; k += LPP) {
+        const double *nd = nodes + dims.off[k];
+        double x = valid ? pts[pidx * dims.d + k] : nd[0];
+        bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + dims.off[k], 1);
+    }
+    __syncthreads();
+    const int d = dims.d;
+    const int K = dims.n[d - 1];
+    long M = 1;
+    for (int k = 0; k < d - 1; ++k) M *= dims.n[k];
+    const double *bl = bw + dims.off[d - 1];
+    double acc = 0.0;
+    for (long m = sub; m < M; m += LPP) {
+        double w = 1.0;
+        long rem = m;
+        for (int k = d - 2; k >= 0; --k) {
+            int nk = dims.n[k];
+            int i = (int)(rem % nk);
+            rem /= nk;
+            w *= bw[dims.off[k] + i];
+        }
+        const double *row = T + m * K;
+        double s = 0.0;
+        for (int j = 0; j < K; ++j) s = __builtin_fma(row[j], bl[j], s);
+        acc = __builtin_fma(s, w, acc);
+    }
+    for (int o = LPP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (sub == 0 && valid) out[pidx * ostride + ooff] = acc;
+}

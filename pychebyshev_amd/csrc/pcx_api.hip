@@ -1,0 +1,812 @@
+// pcx_api.hip -- C ABI of libpcx_hip.so (see include/pcx.h).  gfx950 only.
+//
+// Host side: argument validation, device buffers, launch planning, kernel launches.
+// No CPU arithmetic fallback lives here: every numeric result comes from a HIP kernel.
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "bary_kernels.h"
+#include "tt_kernels.h"
+#include "ttcross_kernels.h"
+
+// ---------------------------------------------------------------------------------
+// errors
+// ---------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(PCX_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                               \
+    } while (0)
+
+static int use_device(int device) {
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess || cnt <= 0)
+        return fail(PCX_ERR_NO_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= cnt)
+        return fail(PCX_ERR_NO_DEVICE, "device %d out of range [0, %d)", device, cnt);
+    HIP_TRY(hipSetDevice(device));
+    return PCX_OK;
+}
+
+extern "C" int pcx_abi_version(void) { return PCX_ABI_VERSION; }
+extern "C" const char *pcx_last_error(void) { return g_err; }
+
+extern "C" int pcx_device_count(int *n) {
+    if (!n) return fail(PCX_ERR_INVALID, "n is NULL");
+    int cnt = 0;
+    hipError_t e = hipGetDeviceCount(&cnt);
+    if (e != hipSuccess) { *n = 0; return fail(PCX_ERR_NO_DEVICE, "%s", hipGetErrorString(e)); }
+    *n = cnt;
+    return PCX_OK;
+}
+
+extern "C" int pcx_device_info(int device, char *name, int name_len, int *cus, int64_t *hbm) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (name && name_len > 0) snprintf(name, (size_t)name_len, "%s (%s)", prop.name, prop.gcnArchName);
+    if (cus) *cus = prop.multiProcessorCount;
+    if (hbm) *hbm = (int64_t)prop.totalGlobalMem;
+    return PCX_OK;
+}
+
+extern "C" int pcx_dev_malloc(int device, size_t bytes, void **dptr) {
+    if (!dptr) return fail(PCX_ERR_INVALID, "dptr is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 8));
+    return PCX_OK;
+}
+extern "C" int pcx_dev_free(int device, void *dptr) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    if (dptr) HIP_TRY(hipFree(dptr));
+    return PCX_OK;
+}
+extern "C" int pcx_memcpy_h2d(int device, void *dst, const void *src, size_t bytes) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return PCX_OK;
+}
+extern "C" int pcx_memcpy_d2h(int device, void *dst, const void *src, size_t bytes) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+extern "C" int pcx_device_synchronize(int device) {
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipDeviceSynchronize());
+    return PCX_OK;
+}
+extern "C" int pcx_event_create(int device, void **event) {
+    if (!event) return fail(PCX_ERR_INVALID, "event is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipEvent_t ev;
+    HIP_TRY(hipEventCreate(&ev));
+    *event = (void *)ev;
+    return PCX_OK;
+}
+extern "C" int pcx_event_record(void *event, void *stream) {
+    if (!event) return fail(PCX_ERR_INVALID, "event is NULL");
+    HIP_TRY(hipEventRecord((hipEvent_t)event, (hipStream_t)stream));
+    return PCX_OK;
+}
+extern "C" int pcx_event_elapsed_ms(void *start, void *stop, float *ms) {
+    if (!start || !stop || !ms) return fail(PCX_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipEventSynchronize((hipEvent_t)stop));
+    HIP_TRY(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PCX_OK;
+}
+extern "C" int pcx_event_destroy(void *event) {
+    if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return PCX_OK;
+}
+
+// grow-only device scratch used by the host-pointer entry points
+struct Scratch {
+    void *ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return PCX_OK;
+        if (ptr) { (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+        hipError_t e = hipMalloc(&ptr, bytes);
+        if (e != hipSuccess) { ptr = nullptr; return fail(PCX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        cap = bytes;
+        return PCX_OK;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
+};
+
+// Host-pointer batches are processed in chunks so the staging buffers stay bounded.
+static const int64_t kChunkPoints = 1 << 23;
+
+// ---------------------------------------------------------------------------------
+// barycentric handle
+// ---------------------------------------------------------------------------------
+struct DerivedTensor {
+    double *plain = nullptr;  // C-order tensor after the derivative passes (prod n doubles)
+    double *frag = nullptr;   // MFMA A-fragment packing of `plain` (MT*KS*64 doubles) or NULL
+};
+
+struct pcx_bary {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    BaryDims dims;
+    long total = 0;
+    std::vector<int> doff;           // offsets of D_k in diff_cat
+    double *d_nodes = nullptr, *d_wts = nullptr, *d_diff = nullptr;
+    // launch plan
+    bool mfma_ok = false;
+    BaryMfmaPlan plan;
+    int nt = 2;                      // point tiles per wave in the MFMA kernel
+    unsigned *d_rowcode = nullptr, *d_kcode = nullptr;
+    int lpp = 64;                    // lanes per point in the rows kernel
+    int variant = 0;                 // 0 auto, 1 rows, 2 mfma
+    std::mutex mu;
+    std::map<std::vector<int>, DerivedTensor> cache;
+    Scratch s_pts, s_out;
+};
+
+static const int kKsList[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 31, 32};
+
+static int pick_ks(int K) {
+    int need = (K + 3) / 4;
+    for (int ks : kKsList)
+        if (ks >= need) return ks;
+    return -1;
+}
+
+// choose the head/tail split minimising the number of MFMAs (MT * KS)
+static bool plan_mfma(const BaryDims &dm, BaryMfmaPlan &best) {
+    bool found = false;
+    long best_cost = 0;
+    for (int split = std::max(0, dm.d - PCX_CODE_FIELDS); split < dm.d; ++split) {
+        if (split > PCX_CODE_FIELDS) continue;  // head dims must fit one row code
+        long M = 1, K = 1;
+        for (int k = 0; k < split; ++k) M *= dm.n[k];
+        for (int k = split; k < dm.d; ++k) K *= dm.n[k];
+        if (K > 128 || M > (1 << 24)) continue;
+        int ks = pick_ks((int)K);
+        if (ks < 0) continue;
+        long mt = (M + 15) / 16;
+        long cost = mt * ks;
+        if (!found || cost < best_cost || (cost == best_cost && K > best.K)) {
+            found = true;
+            best_cost = cost;
+            best.split = split; best.M = (int)M; best.K = (int)K; best.MT = (int)mt; best.KS = ks;
+        }
+    }
+    return found;
+}
+
+static size_t mfma_lds_bytes(const BaryDims &dm, int nt) {
+    return (size_t)4 * (dm.sum_n + 1) * 16 * nt * sizeof(double);
+}
+
+extern "C" int pcx_bary_destroy(pcx_bary *h) {
+    if (!h) return PCX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &kv : h->cache) {
+        if (kv.second.plain) (void)hipFree(kv.second.plain);
+        if (kv.second.frag) (void)hipFree(kv.second.frag);
+    }
+    (void)hipFree(h->d_nodes); (void)hipFree(h->d_wts); (void)hipFree(h->d_diff);
+    (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
+    h->s_pts.release(); h->s_out.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PCX_OK;
+}
+
+static int bary_pack(pcx_bary *h, DerivedTensor &dt) {
+    if (!h->mfma_ok) return PCX_OK;
+    const BaryMfmaPlan &p = h->plan;
+    size_t cnt = (size_t)p.MT * p.KS * 64;
+    HIP_TRY(hipMalloc((void **)&dt.frag, cnt * sizeof(double)));
+    int blocks = (int)((cnt + 255) / 256);
+    hipLaunchKernelGGL(k_pack_fragments, dim3(blocks), dim3(256), 0, h->stream, dt.plain, dt.frag,
+                       p.M, p.K, p.MT, p.KS);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const double *nodes_cat,
+                               const double *weights_cat, const double *diffmat_cat,
+                               const double *tensor, pcx_bary **out) {
+    if (!out) return fail(PCX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (d < 1 || d > PCX_MAX_DIMS) return fail(PCX_ERR_INVALID, "d=%d outside [1, %d]", d, PCX_MAX_DIMS);
+    if (!n_nodes || !nodes_cat || !weights_cat || !diffmat_cat || !tensor)
+        return fail(PCX_ERR_INVALID, "NULL model array");
+    int rc = use_device(device);
+    if (rc) return rc;
+    pcx_bary *h = new (std::nothrow) pcx_bary();
+    if (!h) return fail(PCX_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->dims.d = d;
+    long total = 1, sum_n = 0, sum_n2 = 0;
+    for (int k = 0; k < d; ++k) {
+        if (n_nodes[k] < 1 || n_nodes[k] > 4096) { delete h; return fail(PCX_ERR_INVALID, "n_nodes[%d]=%d outside [1, 4096]", k, n_nodes[k]); }
+        h->dims.n[k] = n_nodes[k];
+        h->dims.off[k] = (int)sum_n;
+        h->doff.push_back((int)sum_n2);
+        sum_n += n_nodes[k];
+        sum_n2 += (long)n_nodes[k] * n_nodes[k];
+        total *= n_nodes[k];
+        if (total > (1L << 33)) { delete h; return fail(PCX_ERR_UNSUPPORTED, "tensor larger than 2^33 elements"); }
+    }
+    for (int k = d; k < PCX_MAX_DIMS; ++k) { h->dims.n[k] = 1; h->dims.off[k] = 0; }
+    h->dims.sum_n = (int)sum_n;
+    h->total = total;
+
+#define CREATE_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            int c_ = fail(PCX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+            pcx_bary_destroy(h);                                                           \
+            return c_;                                                                     \
+        }                                                                                  \
+    } while (0)
+
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc((void **)&h->d_nodes, sum_n * sizeof(double)));
+    CREATE_TRY(hipMalloc((void **)&h->d_wts, sum_n * sizeof(double)));
+    CREATE_TRY(hipMalloc((void **)&h->d_diff, sum_n2 * sizeof(double)));
+    CREATE_TRY(hipMemcpy(h->d_nodes, nodes_cat, sum_n * sizeof(double), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_wts, weights_cat, sum_n * sizeof(double), hipMemcpyHostToDevice));
+    CREATE_TRY(hipMemcpy(h->d_diff, diffmat_cat, sum_n2 * sizeof(double), hipMemcpyHostToDevice));
+
+    // rows kernel geometry: lanes per point = smallest power of two >= number of rows
+    long Mrows = total / h->dims.n[d - 1];
+    int lpp = 1;
+    while (lpp < 64 && lpp < Mrows) lpp <<= 1;
+    h->lpp = lpp;
+
+    // MFMA plan + row/k codes
+    h->mfma_ok = (sum_n <= PCX_MAX_SUM_N) && plan_mfma(h->dims, h->plan);
+    if (h->mfma_ok) {
+        h->nt = 2;
+        if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->nt = 1;
+        if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->mfma_ok = false;
+    }
+    if (h->mfma_ok) {
+        const BaryMfmaPlan &p = h->plan;
+        const unsigned ones = (unsigned)sum_n;  // index of the all-ones table row
+        std::vector<unsigned> rowcode((size_t)p.MT * 16), kcode((size_t)p.KS * 4);
+        for (long m = 0; m < (long)p.MT * 16; ++m) {
+            unsigned f[PCX_CODE_FIELDS] = {ones, ones, ones, ones};
+            if (m < p.M) {
+                long rem = m;
+                for (int k = p.split - 1; k >= 0; --k) {
+                    int i = (int)(rem % h->dims.n[k]);
+                    rem /= h->dims.n[k];
+                    f[k] = (unsigned)(h->dims.off[k] + i);
+                }
+            }
+            rowcode[m] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
+        }
+        for (long kk = 0; kk < (long)p.KS * 4; ++kk) {
+            unsigned f[PCX_CODE_FIELDS] = {ones, ones, ones, ones};
+            if (kk < p.K) {
+                long rem = kk;
+                for (int k = d - 1; k >= p.split; --k) {
+                    int i = (int)(rem % h->dims.n[k]);
+                    rem /= h->dims.n[k];
+                    f[k - p.split] = (unsigned)(h->dims.off[k] + i);
+                }
+            }
+            kcode[kk] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
+        }
+        CREATE_TRY(hipMalloc((void **)&h->d_rowcode, rowcode.size() * sizeof(unsigned)));
+        CREATE_TRY(hipMalloc((void **)&h->d_kcode, kcode.size() * sizeof(unsigned)));
+        CREATE_TRY(hipMemcpy(h->d_rowcode, rowcode.data(), rowcode.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        CREATE_TRY(hipMemcpy(h->d_kcode, kcode.data(), kcode.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+    }
+
+    // value tensor (derivative spec all-zero) enters the cache at create
+    DerivedTensor dt;
+    CREATE_TRY(hipMalloc((void **)&dt.plain, total * sizeof(double)));
+    CREATE_TRY(hipMemcpy(dt.plain, tensor, total * sizeof(double), hipMemcpyHostToDevice));
+    rc = bary_pack(h, dt);
+    if (rc) { (void)hipFree(dt.plain); pcx_bary_destroy(h); return rc; }
+    h->cache[std::vector<int>(d, 0)] = dt;
+    CREATE_TRY(hipStreamSynchronize(h->stream));
+#undef CREATE_TRY
+    *out = h;
+    return PCX_OK;
+}
+
+// Returns (building on first use) the derivative-transformed tensor for `deriv`.
+// Caller holds h->mu.  Work is enqueued on h->stream.
+static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **out) {
+    const int d = h->dims.d;
+    std::vector<int> key(d, 0);
+    if (deriv)
+        for (int k = 0; k < d; ++k) {
+            if (deriv[k] < 0 || deriv[k] > 8) return fail(PCX_ERR_INVALID, "derivative order %d at dim %d outside [0, 8]", deriv[k], k);
+            key[k] = deriv[k];
+        }
+    auto it = h->cache.find(key);
+    if (it != h->cache.end()) { *out = &it->second; return PCX_OK; }
+    if (h->cache.size() > 64) return fail(PCX_ERR_UNSUPPORTED, "more than 64 distinct derivative specs cached on one handle");
+
+    DerivedTensor &base = h->cache[std::vector<int>(d, 0)];
+    double *cur = nullptr, *tmp = nullptr;
+    HIP_TRY(hipMalloc((void **)&cur, h->total * sizeof(double)));
+    if (hipMalloc((void **)&tmp, h->total * sizeof(double)) != hipSuccess) { (void)hipFree(cur); return fail(PCX_ERR_NOMEM, "hipMalloc failed"); }
+    HIP_TRY(hipMemcpyAsync(cur, base.plain, h->total * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    // barycentric.py:982-989: dims descending, order[k] passes each
+    for (int k = d - 1; k >= 0; --k) {
+        long outer = 1, inner = 1;
+        for (int q = 0; q < k; ++q) outer *= h->dims.n[q];
+        for (int q = k + 1; q < d; ++q) inner *= h->dims.n[q];
+        for (int r = 0; r < key[k]; ++r) {
+            int blocks = (int)((h->total + 255) / 256);
+            hipLaunchKernelGGL(k_mode_product, dim3(blocks), dim3(256), 0, h->stream, cur, tmp,
+                               h->d_diff + h->doff[k], outer, h->dims.n[k], inner);
+            std::swap(cur, tmp);
+        }
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    (void)hipFree(tmp);
+    DerivedTensor dt;
+    dt.plain = cur;
+    int rc = bary_pack(h, dt);
+    if (rc) { (void)hipFree(cur); return rc; }
+    auto ins = h->cache.emplace(key, dt);
+    *out = &ins.first->second;
+    return PCX_OK;
+}
+
+template <int KS, int NT>
+static int launch_mfma_t(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
+                         double *d_out, long ostride, long ooff, hipStream_t st) {
+    size_t lds = mfma_lds_bytes(h->dims, NT);
+    auto kern = k_bary_mfma<KS, NT>;
+    static thread_local size_t set_for = 0;
+    if (lds > 64 * 1024 || set_for < lds) {
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        set_for = lds;
+    }
+    long per_wg = 4L * 16 * NT;
+    long blocks = (N + per_wg - 1) / per_wg;
+    if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->plan, h->d_nodes,
+                       h->d_wts, dt.frag, h->d_rowcode, h->d_kcode, d_pts, d_out, N, ostride, ooff);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+template <int NT>
+static int launch_mfma_nt(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
+                          double *d_out, long ostride, long ooff, hipStream_t st) {
+    switch (h->plan.KS) {
+#define CASE_KS(v) case v: return launch_mfma_t<v, NT>(h, dt, d_pts, N, d_out, ostride, ooff, st);
+        CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(6) CASE_KS(8) CASE_KS(12) CASE_KS(16)
+        CASE_KS(20) CASE_KS(24) CASE_KS(28) CASE_KS(31) CASE_KS(32)
+#undef CASE_KS
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d", h->plan.KS);
+}
+
+static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
+                       double *d_out, long ostride, long ooff, hipStream_t st) {
+    int ppw = 256 / h->lpp;
+    size_t lds = (size_t)ppw * h->dims.sum_n * sizeof(double);
+    if (lds > 64 * 1024) return fail(PCX_ERR_UNSUPPORTED, "sum of node counts %d too large for the rows kernel", h->dims.sum_n);
+    long blocks = (N + ppw - 1) / ppw;
+    if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL(k_bary_rows, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->lpp,
+                       h->d_nodes, h->d_wts, dt.plain, d_pts, d_out, N, ostride, ooff);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+static int bary_launch(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
+                       double *d_out, long ostride, long ooff, hipStream_t st) {
+    if (N == 0) return PCX_OK;
+    int variant = h->variant;
+    if (variant == 0) variant = h->mfma_ok ? 2 : 1;
+    if (variant == 2) {
+        if (!h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
+        return h->nt == 2 ? launch_mfma_nt<2>(h, dt, d_pts, N, d_out, ostride, ooff, st)
+                          : launch_mfma_nt<1>(h, dt, d_pts, N, d_out, ostride, ooff, st);
+    }
+    return launch_rows(h, dt, d_pts, N, d_out, ostride, ooff, st);
+}
+
+extern "C" int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t N,
+                                       const int32_t *deriv, double *d_out, void *stream) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0) return fail(PCX_ERR_INVALID, "N=%lld < 0", (long long)N);
+    if (N > 0 && (!d_pts || !d_out)) return fail(PCX_ERR_INVALID, "NULL device buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    DerivedTensor *dt = nullptr;
+    int rc = bary_get_tensor(h, deriv, &dt);
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    return bary_launch(h, *dt, d_pts, (long)N, d_out, 1, 0, st);
+}
+
+static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs, int m,
+                          double *out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int d = h->dims.d;
+    std::vector<DerivedTensor *> dts(m);
+    for (int s = 0; s < m; ++s) {
+        int rc = bary_get_tensor(h, derivs ? derivs + (size_t)s * d : nullptr, &dts[s]);
+        if (rc) return rc;
+    }
+    for (int64_t start = 0; start < N; start += kChunkPoints) {
+        long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
+        int rc = h->s_pts.reserve((size_t)cnt * d * sizeof(double));
+        if (rc) return rc;
+        rc = h->s_out.reserve((size_t)cnt * m * sizeof(double));
+        if (rc) return rc;
+        double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
+        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        for (int s = 0; s < m; ++s) {
+            rc = bary_launch(h, *dts[s], dp, cnt, dout, m, s, h->stream);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_eval_batch(pcx_bary *h, const double *pts, int64_t N, const int32_t *deriv,
+                                   double *out) {
+    return bary_eval_host(h, pts, N, deriv, 1, out);
+}
+
+extern "C" int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t N,
+                                         const int32_t *derivs, int m, double *out) {
+    if (!derivs) return fail(PCX_ERR_INVALID, "derivs is NULL");
+    return bary_eval_host(h, pts, N, derivs, m, out);
+}
+
+extern "C" int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, double *tensor_out) {
+    if (!h || !tensor_out) return fail(PCX_ERR_INVALID, "NULL argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    DerivedTensor *dt = nullptr;
+    int rc = bary_get_tensor(h, deriv, &dt);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    HIP_TRY(hipMemcpy(tensor_out, dt->plain, h->total * sizeof(double), hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (variant < 0 || variant > 2) return fail(PCX_ERR_INVALID, "variant %d outside [0, 2]", variant);
+    if (variant == 2 && !h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->variant = variant;
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
+    if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
+    info[0] = h->mfma_ok ? 2 : 1;
+    info[1] = h->mfma_ok ? h->plan.MT : 0;
+    info[2] = h->mfma_ok ? h->plan.KS : 0;
+    info[3] = h->mfma_ok ? (int32_t)mfma_lds_bytes(h->dims, h->nt) : (256 / h->lpp) * h->dims.sum_n * 8;
+    info[4] = h->mfma_ok ? 64 * h->nt : 256 / h->lpp;
+    info[5] = h->mfma_ok ? h->plan.split : h->dims.d - 1;
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_stream(pcx_bary *h, void **stream) {
+    if (!h || !stream) return fail(PCX_ERR_INVALID, "NULL argument");
+    *stream = (void *)h->stream;
+    return PCX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// tensor-train handle
+// ---------------------------------------------------------------------------------
+struct pcx_tt {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    TTDims dims;
+    TTRanks rk;
+    int rmax = 1;
+    int cls = 0;  // 0: RC<=4,RT=1,NT=4   1: RC<=8,RT=2,NT=2   2: RC<=16,RT=4,NT=1
+    double *d_frag = nullptr;
+    std::mutex mu;
+    Scratch s_pts, s_out;
+};
+
+extern "C" int pcx_tt_destroy(pcx_tt *h) {
+    if (!h) return PCX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_frag);
+    h->s_pts.release(); h->s_out.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PCX_OK;
+}
+
+extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const int32_t *ranks,
+                             const double *lo, const double *hi, const double *cores_cat,
+                             const int32_t *dim_order, pcx_tt **out) {
+    if (!out) return fail(PCX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (d < 1 || d > PCX_MAX_DIMS) return fail(PCX_ERR_INVALID, "d=%d outside [1, %d]", d, PCX_MAX_DIMS);
+    if (!n_nodes || !ranks || !lo || !hi || !cores_cat) return fail(PCX_ERR_INVALID, "NULL model array");
+    if (ranks[0] != 1 || ranks[d] != 1) return fail(PCX_ERR_INVALID, "boundary TT ranks must be 1");
+    int rc = use_device(device);
+    if (rc) return rc;
+    pcx_tt *h = new (std::nothrow) pcx_tt();
+    if (!h) return fail(PCX_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->dims.d = d;
+    std::vector<char> seen(d, 0);
+    long frag_total = 0, core_total = 0;
+    std::vector<long> coff(d);
+    for (int k = 0; k < d; ++k) {
+        if (n_nodes[k] < 1 || n_nodes[k] > 4096 || ranks[k] < 1 || ranks[k + 1] < 1) { delete h; return fail(PCX_ERR_INVALID, "bad n_nodes/ranks at dim %d", k); }
+        if (!(lo[k] < hi[k])) { delete h; return fail(PCX_ERR_INVALID, "domain[%d]: lo must be < hi", k); }
+        int col = dim_order ? dim_order[k] : k;
+        if (col < 0 || col >= d || seen[col]) { delete h; return fail(PCX_ERR_INVALID, "dim_order is not a permutation"); }
+        seen[col] = 1;
+        h->dims.n[k] = n_nodes[k];
+        h->dims.col[k] = col;
+        h->dims.lo[k] = lo[k];
+        h->dims.hi[k] = hi[k];
+        h->rk.rc[k] = (ranks[k] + 3) / 4;
+        h->rk.rt[k] = (ranks[k + 1] + 15) / 16;
+        h->dims.frag_off[k] = frag_total;
+        frag_total += (long)n_nodes[k] * h->rk.rc[k] * h->rk.rt[k] * 64;
+        coff[k] = core_total;
+        core_total += (long)ranks[k] * n_nodes[k] * ranks[k + 1];
+        h->rmax = std::max(h->rmax, std::max(ranks[k], ranks[k + 1]));
+    }
+    if (h->rmax > 64) { delete h; return fail(PCX_ERR_UNSUPPORTED, "TT rank %d > 64 not covered by the MFMA kernel", h->rmax); }
+    h->cls = h->rmax <= 16 ? 0 : (h->rmax <= 32 ? 1 : 2);
+
+#define CREATE_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) {                                                            \
+            int c_ = fail(PCX_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));     \
+            pcx_tt_destroy(h);                                                             \
+            return c_;                                                                     \
+        }                                                                                  \
+    } while (0)
+    CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CREATE_TRY(hipMalloc((void **)&h->d_frag, frag_total * sizeof(double)));
+    double *d_cores = nullptr;
+    CREATE_TRY(hipMalloc((void **)&d_cores, core_total * sizeof(double)));
+    CREATE_TRY(hipMemcpy(d_cores, cores_cat, core_total * sizeof(double), hipMemcpyHostToDevice));
+    for (int k = 0; k < d; ++k) {
+        long cnt = (long)n_nodes[k] * h->rk.rc[k] * h->rk.rt[k] * 64;
+        hipLaunchKernelGGL(k_tt_pack_core, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream,
+                           d_cores + coff[k], h->d_frag + h->dims.frag_off[k], ranks[k], n_nodes[k],
+                           ranks[k + 1], h->rk.rc[k], h->rk.rt[k]);
+    }
+    hipError_t e1 = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_cores);
+    CREATE_TRY(e1);
+    CREATE_TRY(e2);
+#undef CREATE_TRY
+    *out = h;
+    return PCX_OK;
+}
+
+static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
+    if (N == 0) return PCX_OK;
+    auto go = [&](auto kern, int nt) -> int {
+        long per_wg = 4L * 16 * nt;
+        long blocks = (N + per_wg - 1) / per_wg;
+        if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, h->dims, h->rk, h->d_frag, d_pts, d_out, N);
+        HIP_TRY(hipGetLastError());
+        return PCX_OK;
+    };
+    if (h->cls == 0) {
+        if (h->rmax <= 4) return go(k_tt_eval_mfma<1, 1, 4>, 4);
+        if (h->rmax <= 8) return go(k_tt_eval_mfma<2, 1, 4>, 4);
+        if (h->rmax <= 12) return go(k_tt_eval_mfma<3, 1, 4>, 4);
+        return go(k_tt_eval_mfma<4, 1, 4>, 4);
+    }
+    if (h->cls == 1) return go(k_tt_eval_mfma<8, 2, 2>, 2);
+    return go(k_tt_eval_mfma<16, 4, 1>, 1);
+}
+
+extern "C" int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, double *d_out,
+                                     void *stream) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0) return fail(PCX_ERR_INVALID, "N < 0");
+    if (N > 0 && (!d_pts || !d_out)) return fail(PCX_ERR_INVALID, "NULL device buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    return tt_launch(h, d_pts, (long)N, d_out, stream ? (hipStream_t)stream : h->stream);
+}
+
+extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double *out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0) return fail(PCX_ERR_INVALID, "N < 0");
+    if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int d = h->dims.d;
+    for (int64_t start = 0; start < N; start += kChunkPoints) {
+        long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
+        int rc = h->s_pts.reserve((size_t)cnt * d * sizeof(double));
+        if (rc) return rc;
+        rc = h->s_out.reserve((size_t)cnt * sizeof(double));
+        if (rc) return rc;
+        double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
+        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        rc = tt_launch(h, dp, cnt, dout, h->stream);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + start, dout, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return PCX_OK;
+}
+
+extern "C" int pcx_tt_stream(pcx_tt *h, void **stream) {
+    if (!h || !stream) return fail(PCX_ERR_INVALID, "NULL argument");
+    *stream = (void *)h->stream;
+    return PCX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// TT-Cross build steps
+// ---------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) { p = nullptr; return fail(PCX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        return PCX_OK;
+    }
+    template <typename T> T *as() { return (T *)p; }
+};
+
+extern "C" int pcx_tt_value_to_coeff_core(int device, const double *value_core, int rl, int n, int rr,
+                                          double *coeff_core) {
+    if (!value_core || !coeff_core || rl < 1 || n < 1 || rr < 1) return fail(PCX_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    size_t cnt = (size_t)rl * n * rr;
+    DevBuf in, out;
+    if ((rc = in.alloc(cnt * sizeof(double)))) return rc;
+    if ((rc = out.alloc(cnt * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpy(in.p, value_core, cnt * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_value_to_coeff_core, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0,
+                       in.as<double>(), out.as<double>(), rl, n, rr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(coeff_core, out.p, cnt * sizeof(double), hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+
+extern "C" int pcx_tt_grid_eval(int device, int d, const int32_t *n_nodes, const int32_t *ranks,
+                                const double *value_cores_cat, const int32_t *idx, int count,
+                                double *out) {
+    if (d < 1 || d > PCX_MAX_DIMS || !n_nodes || !ranks || !value_cores_cat || count < 0) return fail(PCX_ERR_INVALID, "bad argument");
+    if (count == 0) return PCX_OK;
+    if (!idx || !out) return fail(PCX_ERR_INVALID, "NULL buffer");
+    int rc = use_device(device);
+    if (rc) return rc;
+    std::vector<long> coff(d);
+    long core_total = 0;
+    int rmax = 1;
+    for (int k = 0; k < d; ++k) {
+        if (n_nodes[k] < 1 || ranks[k] < 1 || ranks[k + 1] < 1) return fail(PCX_ERR_INVALID, "bad n_nodes/ranks at dim %d", k);
+        coff[k] = core_total;
+        core_total += (long)ranks[k] * n_nodes[k] * ranks[k + 1];
+        rmax = std::max(rmax, std::max(ranks[k], ranks[k + 1]));
+    }
+    for (long i = 0; i < (long)count * d; ++i)
+        if (idx[i] < 0 || idx[i] >= n_nodes[i % d]) return fail(PCX_ERR_INVALID, "grid index out of range");
+    DevBuf dn, dr, dc, dcores, didx, dout, dwork;
+    if ((rc = dn.alloc(d * sizeof(int)))) return rc;
+    if ((rc = dr.alloc((d + 1) * sizeof(int)))) return rc;
+    if ((rc = dc.alloc(d * sizeof(long)))) return rc;
+    if ((rc = dcores.alloc(core_total * sizeof(double)))) return rc;
+    if ((rc = didx.alloc((size_t)count * d * sizeof(int)))) return rc;
+    if ((rc = dout.alloc((size_t)count * sizeof(double)))) return rc;
+    if ((rc = dwork.alloc((size_t)count * 2 * rmax * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpy(dn.p, n_nodes, d * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dr.p, ranks, (d + 1) * sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dc.p, coff.data(), d * sizeof(long), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dcores.p, value_cores_cat, core_total * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(didx.p, idx, (size_t)count * d * sizeof(int), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_tt_grid_eval, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, 0, d, dn.as<int>(),
+                       dr.as<int>(), dc.as<long>(), dcores.as<double>(), didx.as<int>(), count,
+                       dout.as<double>(), dwork.as<double>(), rmax);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+
+extern "C" int pcx_maxvol(int device, const double *A, int m, int r, double tol, int max_iters,
+                          int64_t *idx_out) {
+    if (!A || !idx_out || m < 1 || r < 1) return fail(PCX_ERR_INVALID, "bad argument");
+    if (m <= r) {  // tensor_train.py:85-86
+        for (int i = 0; i < m; ++i) idx_out[i] = i;
+        return PCX_OK;
+    }
+    if (r > TTX_MAX_R || m > TTX_MAX_M) return fail(PCX_ERR_UNSUPPORTED, "maxvol: %d x %d exceeds %d x %d", m, r, TTX_MAX_M, TTX_MAX_R);
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf dA, dB, didx;
+    if ((rc = dA.alloc((size_t)m * r * sizeof(double)))) return rc;
+    if ((rc = dB.alloc((size_t)m * r * sizeof(double)))) return rc;
+    if ((rc = didx.alloc((size_t)r * sizeof(long long)))) return rc;
+    HIP_TRY(hipMemcpy(dA.p, A, (size_t)m * r * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_maxvol, dim3(1), dim3(TTX_THREADS), 0, 0, dA.as<double>(), m, r, tol, max_iters,
+                       dB.as<double>(), didx.as<long long>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(idx_out, didx.p, (size_t)r * sizeof(long long), hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+
+extern "C" int pcx_tt_cross_step(int device, const double *C, int m, int c, int cap, double rel_thresh,
+                                 double *chat, int64_t *pivots, int32_t *rank_out) {
+    if (!C || !chat || !pivots || !rank_out || m < 1 || c < 1 || cap < 1) return fail(PCX_ERR_INVALID, "bad argument");
+    if (c > TTX_MAX_R || m > TTX_MAX_M) return fail(PCX_ERR_UNSUPPORTED, "cross step: %d x %d exceeds %d x %d", m, c, TTX_MAX_M, TTX_MAX_R);
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf dC, dU, dB, dchat, dpiv, drank;
+    if ((rc = dC.alloc((size_t)m * c * sizeof(double)))) return rc;
+    if ((rc = dU.alloc((size_t)m * c * sizeof(double)))) return rc;
+    if ((rc = dB.alloc((size_t)m * c * sizeof(double)))) return rc;
+    if ((rc = dchat.alloc((size_t)m * c * sizeof(double)))) return rc;
+    if ((rc = dpiv.alloc((size_t)c * sizeof(long long)))) return rc;
+    if ((rc = drank.alloc(sizeof(int)))) return rc;
+    HIP_TRY(hipMemcpy(dC.p, C, (size_t)m * c * sizeof(double), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_cross_step, dim3(1), dim3(TTX_THREADS), 0, 0, dC.as<double>(), m, c, cap, rel_thresh,
+                       dU.as<double>(), dB.as<double>(), dchat.as<double>(), dpiv.as<long long>(),
+                       drank.as<int>());
+    HIP_TRY(hipGetLastError());
+    int rank = 0;
+    HIP_TRY(hipMemcpy(&rank, drank.p, sizeof(int), hipMemcpyDeviceToHost));
+    if (rank < 1 || rank > c) return fail(PCX_ERR_HIP, "cross step returned rank %d", rank);
+    HIP_TRY(hipMemcpy(chat, dchat.p, (size_t)m * rank * sizeof(double), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pivots, dpiv.p, (size_t)rank * sizeof(long long), hipMemcpyDeviceToHost));
+    *rank_out = rank;
+    return PCX_OK;
+}

@@ -1,0 +1,44 @@
+// pcx_common.h -- shared host/device definitions for libpcx_hip (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/pcx.h"
+
+#define PCX_WAVE 64
+
+typedef double pcx_d4 __attribute__((ext_vector_type(4)));
+
+// Row codes are 4 x 8-bit row indices into the per-wave weight table held in LDS
+// ([sum_n + 1][points] doubles; the extra last row is all ones and pads unused fields).
+#define PCX_MAX_SUM_N 254
+#define PCX_CODE_FIELDS 4
+
+// ---- barycentric kernel parameters (passed by value -> kernarg / SGPRs) ----------
+struct BaryDims {
+    int d;                  // number of dimensions
+    int sum_n;              // sum of n[]
+    int n[PCX_MAX_DIMS];    // nodes per dimension
+    int off[PCX_MAX_DIMS];  // prefix offsets into nodes_cat / weights_cat
+};
+
+// y[p] = sum_m wM[m,p] * sum_k T2[m,k] * wK[k,p] with T2 = tensor viewed as (M x K):
+// dims [0, split) index the rows m (head), dims [split, d) the columns k (tail).
+struct BaryMfmaPlan {
+    int split;
+    int M;    // prod n[0:split]  (1 when split == 0)
+    int K;    // prod n[split:d]
+    int MT;   // row tiles of 16 covering M
+    int KS;   // k-steps of 4 run by the kernel instantiation (KS*4 >= K)
+};
+
+// ---- tensor-train kernel parameters ---------------------------------------------
+struct TTDims {
+    int d;
+    int n[PCX_MAX_DIMS];
+    int col[PCX_MAX_DIMS];        // user column read by storage position k (dim_order)
+    double lo[PCX_MAX_DIMS];
+    double hi[PCX_MAX_DIMS];
+    long frag_off[PCX_MAX_DIMS];  // offset (doubles) of storage dim k in the packed cores
+};
