@@ -1,0 +1,550 @@
+"""``ChebyshevApproximation`` -- full-tensor barycentric Chebyshev interpolant whose
+evaluation runs on an MI355X through ``libpcx_hip.so``.
+
+Host-side mirror of the reference class (``/root/reference/src/pychebyshev/barycentric.py``,
+v0.21.1): same constructor signature, attributes, method names, argument meaning and
+error behaviour for the evaluation path
+
+    eval / vectorized_eval / vectorized_eval_batch / vectorized_eval_multi   (:717-1112)
+    get_derivative_id / _resolve_derivative_args                             (:1173-1243)
+    build (fixed grid) / from_values / nodes                                 (:523-715, :1700-1934)
+    pickle state                                                             (:1523-1574)
+
+Every numeric evaluation is a HIP kernel launch (``pcx_bary_*``); there is no NumPy or
+CPU fallback -- if the library or a device is missing the call raises.  Grid metadata
+(nodes, weights, differentiation matrices) is tiny, host-built once with NumPy exactly
+as the reference builds it, and copied to the device when the first evaluation happens.
+
+Out of scope in this tier (raise ``NotImplementedError``): error-threshold auto-N,
+``special_points`` with knots (spline dispatch), algebra/calculus/extrude/slice.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import pickle
+import time
+import warnings
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+from numpy.polynomial.chebyshev import chebpts1
+
+from . import _lib
+from ._version import __version__
+
+__all__ = [
+    "ChebyshevApproximation",
+    "compute_barycentric_weights",
+    "compute_differentiation_matrix",
+    "chebyshev_nodes",
+]
+
+
+# --------------------------------------------------------------------------------------
+# 1-D grid metadata (host, NumPy; built once per interpolant)
+# --------------------------------------------------------------------------------------
+
+def chebyshev_nodes(lo: float, hi: float, n: int) -> np.ndarray:
+    """Type-I Chebyshev nodes mapped to ``[lo, hi]``, ascending.
+
+    Same arithmetic as the reference's ``_generate_nodes`` (barycentric.py:440-452) and
+    ``_make_nodes_for_dim`` (_extrude_slice.py:66-70): affine map of ``chebpts1(n)``
+    followed by a sort.
+    """
+    return np.sort(0.5 * (lo + hi) + 0.5 * (hi - lo) * chebpts1(n))
+
+
+def compute_barycentric_weights(nodes: np.ndarray) -> np.ndarray:
+    """``w_i = 1 / prod_{j != i} (x_i - x_j)`` as a division chain with j ascending
+    (reference barycentric.py:30-49 -- bit-identical result, one NumPy op per j)."""
+    x = np.asarray(nodes, dtype=float)
+    n = x.size
+    w = np.ones(n)
+    rows = np.arange(n)
+    for j in range(n):
+        keep = rows != j
+        w[keep] /= (x[keep] - x[j])
+    return w
+
+
+def compute_differentiation_matrix(nodes: np.ndarray, weights: np.ndarray) -> np.ndarray:
+    """Spectral differentiation matrix of the barycentric interpolant
+    (Berrut & Trefethen 2004, section 9.3; reference barycentric.py:52-77):
+    ``D_ij = (w_j / w_i) / (x_i - x_j)`` for i != j and ``D_ii = -sum_{j != i} D_ij``."""
+    x = np.asarray(nodes, dtype=float)
+    w = np.asarray(weights, dtype=float)
+    gap = x[:, None] - x[None, :]
+    np.fill_diagonal(gap, 1.0)
+    D = w[None, :] / (gap * w[:, None])
+    np.fill_diagonal(D, 0.0)
+    np.fill_diagonal(D, -D.sum(axis=1))
+    return D
+
+
+def _unwrap_typed(domain, n_nodes, special_points):
+    from . import Domain, Ns, SpecialPoints
+    if isinstance(domain, Domain):
+        domain = list(domain.bounds)
+    if isinstance(n_nodes, Ns):
+        n_nodes = list(n_nodes.counts)
+    if isinstance(special_points, SpecialPoints):
+        special_points = [list(k) for k in special_points.knots_per_dim]
+    return domain, n_nodes, special_points
+
+
+class _DeviceModel:
+    """Owner of one ``pcx_bary`` handle (freed on garbage collection)."""
+
+    def __init__(self, approx: "ChebyshevApproximation", device: int):
+        lib = _lib.load()
+        d = approx.num_dimensions
+        n = _lib.i32(approx.n_nodes)
+        nodes = _lib.f64(np.concatenate([np.asarray(x, dtype=float) for x in approx.nodes]))
+        wts = _lib.f64(np.concatenate([np.asarray(x, dtype=float) for x in approx.weights]))
+        diff = _lib.f64(np.concatenate([np.asarray(x, dtype=float).ravel() for x in approx.diff_matrices]))
+        tensor = _lib.f64(approx.tensor_values)
+        if tensor.shape != tuple(int(v) for v in approx.n_nodes):
+            raise ValueError(f"tensor_values.shape={tensor.shape} does not match n_nodes={tuple(approx.n_nodes)}")
+        handle = ctypes.c_void_p()
+        _lib.check(lib.pcx_bary_create(device, d, _lib.p_i32(n), _lib.p_f64(nodes), _lib.p_f64(wts),
+                                       _lib.p_f64(diff), _lib.p_f64(tensor), ctypes.byref(handle)), lib)
+        self.lib = lib
+        self.handle = handle
+        self.device = device
+        self.tensor_id = id(approx.tensor_values)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pcx_bary_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ChebyshevApproximation:
+    """Multi-dimensional Chebyshev interpolant evaluated on the GPU.
+
+    Parameters mirror the reference (barycentric.py:341-355).  ``function(point, data)``
+    receives a ``list[float]`` and ``additional_data`` and returns a float.
+    """
+
+    def __new__(cls, function=None, num_dimensions=None, domain=None, n_nodes=None,
+                max_derivative_order=2, error_threshold=None, max_n=64, special_points=None,
+                additional_data=None, *, defer_build=False, n_workers=None):
+        _, _, sp = _unwrap_typed(domain, n_nodes, special_points)
+        if sp is not None:
+            if num_dimensions is not None and len(sp) != num_dimensions:
+                raise ValueError(f"special_points must have {num_dimensions} entries, got {len(sp)}")
+            for d, knots in enumerate(sp):
+                if not isinstance(knots, (list, tuple)):
+                    raise ValueError(f"special_points[{d}] must be a list/tuple of floats, "
+                                     f"got {type(knots).__name__}: {knots!r}")
+            if any(len(knots) > 0 for knots in sp):
+                # the reference dispatches to ChebyshevSpline here (barycentric.py:321-338)
+                raise NotImplementedError(
+                    "special_points with knots dispatch to ChebyshevSpline in the reference; "
+                    "piecewise interpolants are outside this build's hot-path scope")
+        return super().__new__(cls)
+
+    def __init__(self, function: Callable, num_dimensions: int,
+                 domain: Sequence[Tuple[float, float]], n_nodes: Sequence[int] | None = None,
+                 max_derivative_order: int = 2, error_threshold: float | None = None,
+                 max_n: int = 64, special_points=None, additional_data: object = None, *,
+                 defer_build: bool = False, n_workers: int | None = None):
+        domain, n_nodes, special_points = _unwrap_typed(domain, n_nodes, special_points)
+        self.function = function
+        self.num_dimensions = num_dimensions
+        self.domain = domain
+        self.error_threshold = error_threshold
+        if max_n < 3:
+            raise ValueError(f"max_n must be at least 3 (the initial N of the doubling loop), "
+                             f"got max_n={max_n}. For a grid smaller than 3 per dimension, pass "
+                             f"n_nodes explicitly instead of using error-threshold auto-calibration.")
+        self.max_n = max_n
+        self.max_derivative_order = max_derivative_order
+        self.special_points = special_points
+        self.descriptor = ""
+        self.additional_data = additional_data
+        if n_workers is not None and (not isinstance(n_workers, int) or n_workers == 0 or n_workers < -1):
+            raise ValueError(f"n_workers must be None, -1, or a positive int, got {n_workers!r}")
+        self.n_workers = n_workers
+        self._derivative_id_registry: dict = {}
+        self._derivative_id_to_orders: list = []
+
+        if n_nodes is None:
+            if error_threshold is None and not defer_build:
+                raise ValueError("Must provide either n_nodes (explicit) or error_threshold "
+                                 "(auto-N). Got neither.")
+            n_nodes = [None] * num_dimensions
+        else:
+            n_nodes = list(n_nodes)
+            if any(n is None for n in n_nodes) and error_threshold is None:
+                raise ValueError("None entries in n_nodes require error_threshold to be set "
+                                 "(auto-N mode).")
+        self.n_nodes = n_nodes
+        self._original_n_nodes = list(n_nodes)
+
+        self.tensor_values: np.ndarray | None = None
+        self.weights: List[np.ndarray] | None = None
+        self.diff_matrices: List[np.ndarray] | None = None
+        self.build_time = 0.0
+        self.n_evaluations = 0
+        self._cached_error_estimate = None
+        self._device_model: _DeviceModel | None = None
+        self._device_index: int | None = None
+
+        if defer_build:
+            if function is not None:
+                raise ValueError("defer_build=True requires function=None (the deferred-construction "
+                                 "workflow expects values to be supplied via "
+                                 "set_original_function_values() later)")
+            if any(not isinstance(n, int) or n <= 0 for n in self.n_nodes):
+                raise ValueError("defer_build=True requires explicit positive int n_nodes; "
+                                 "auto-N (error_threshold) is not supported in deferred mode")
+            self._init_grid_metadata()
+            return
+
+        self.nodes: List[np.ndarray] = []
+        if all(n is not None for n in self.n_nodes):
+            self._generate_nodes()
+
+    # ---------------------------------------------------------------- grid + build
+    def _generate_nodes(self) -> None:
+        self.nodes = [chebyshev_nodes(lo, hi, n) for (lo, hi), n in zip(self.domain, self.n_nodes)]
+
+    def _init_grid_metadata(self) -> None:
+        self._generate_nodes()
+        self.weights = [compute_barycentric_weights(x) for x in self.nodes]
+        self.diff_matrices = [compute_differentiation_matrix(x, w)
+                              for x, w in zip(self.nodes, self.weights)]
+
+    def set_original_function_values(self, values) -> None:
+        """Fill a ``defer_build=True`` interpolant with explicit grid values
+        (reference barycentric.py:484-521)."""
+        if self.tensor_values is not None:
+            raise RuntimeError("interpolant is already constructed; "
+                               "set_original_function_values() is for defer_build=True objects")
+        arr = np.asarray(values, dtype=np.float64)
+        if arr.shape != tuple(self.n_nodes):
+            raise ValueError(f"values shape {arr.shape} does not match expected {tuple(self.n_nodes)}")
+        if not np.isfinite(arr).all():
+            raise ValueError("values contains NaN or Inf (must be finite)")
+        self.tensor_values = arr.copy()
+        self.function = None
+        self._device_model = None
+
+    def build(self, verbose: bool | int = True) -> None:
+        """Evaluate ``function`` on the full grid (C-order) and prepare the interpolant
+        (reference barycentric.py:523-565 -> :647-715).  Host-side by nature: the Python
+        callback is the cost."""
+        if self.function is None:
+            raise RuntimeError("Cannot build: no function assigned. "
+                               "This object was created via from_values() or load().")
+        if any(n is None for n in self._original_n_nodes):
+            raise NotImplementedError("error_threshold auto-N builds are outside this build's "
+                                      "hot-path scope; pass explicit n_nodes")
+        total = int(np.prod(self.n_nodes))
+        if verbose:
+            print(f"Building {self.num_dimensions}D Chebyshev approximation ({total:,} evaluations)...")
+        start = time.time()
+        self._cached_error_estimate = None
+        values = np.zeros(self.n_nodes)
+        fn, data, grid = self.function, self.additional_data, self.nodes
+        for idx in np.ndindex(*self.n_nodes):
+            values[idx] = float(fn([grid[d][i] for d, i in enumerate(idx)], data))
+        self.n_evaluations = total
+        if not np.isfinite(values).all():
+            n_bad = int(np.sum(~np.isfinite(values)))
+            raise ValueError(f"function returned non-finite values at {n_bad} grid point(s); "
+                             "build cannot proceed with NaN/Inf in tensor_values")
+        self.tensor_values = values
+        self.weights = [compute_barycentric_weights(x) for x in self.nodes]
+        self.diff_matrices = [compute_differentiation_matrix(x, w)
+                              for x, w in zip(self.nodes, self.weights)]
+        self._device_model = None
+        self.build_time = time.time() - start
+        if verbose:
+            total_weights = sum(len(w) for w in self.weights)
+            print(f"  Built in {self.build_time:.3f}s ({total_weights} weights, {total_weights * 8} bytes)")
+
+    # ---------------------------------------------------------------- device plumbing
+    def to_device(self, device: int | None = None) -> "ChebyshevApproximation":
+        """Upload (or re-upload) the model to GPU ``device`` (default: ``PCX_DEVICE`` /
+        ``LOCAL_RANK`` / 0).  Called lazily by the first evaluation."""
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        dev = _lib.default_device() if device is None else int(device)
+        self._device_index = dev
+        self._device_model = _DeviceModel(self, dev)
+        return self
+
+    def invalidate_device_cache(self) -> None:
+        """Drop the device copy (call after mutating ``tensor_values`` in place)."""
+        self._device_model = None
+
+    def _model(self) -> _DeviceModel:
+        m = self._device_model
+        if m is None or m.tensor_id != id(self.tensor_values):
+            self.to_device(self._device_index)
+            m = self._device_model
+        return m
+
+    def _check_orders(self, orders) -> np.ndarray:
+        arr = np.asarray(orders)
+        if arr.shape != (self.num_dimensions,):
+            raise ValueError(f"derivative_order must have {self.num_dimensions} entries, got {list(np.shape(orders))}")
+        return _lib.i32(arr)
+
+    def _eval_points(self, pts: np.ndarray, orders) -> np.ndarray:
+        m = self._model()
+        pts = _lib.f64(pts)
+        if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
+            raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
+        out = np.empty(pts.shape[0])
+        spec = self._check_orders(orders)
+        _lib.check(m.lib.pcx_bary_eval_batch(m.handle, _lib.p_f64(pts), pts.shape[0],
+                                             _lib.p_i32(spec), _lib.p_f64(out)), m.lib)
+        return out
+
+    # ---------------------------------------------------------------- evaluation API
+    def eval(self, point, derivative_order=None, *, derivative_id=None) -> float:
+        """Reference ``eval`` (barycentric.py:717-787): the scalar-definition path.  Same
+        result to 1e-12 as :meth:`vectorized_eval`; derivative orders above 2 raise
+        ``ValueError`` as the reference's ``barycentric_derivative_analytical`` does."""
+        derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        for o in derivative_order:
+            if o not in (0, 1, 2):
+                raise ValueError(f"Derivative order {o} not supported (use 1 or 2)")
+        return float(self._eval_points(np.asarray([point], dtype=float), derivative_order)[0])
+
+    def vectorized_eval(self, point, derivative_order=None, *, derivative_id=None) -> float:
+        """Reference ``vectorized_eval`` (barycentric.py:885-949), one point."""
+        derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        return float(self._eval_points(np.asarray([point], dtype=float), derivative_order)[0])
+
+    def vectorized_eval_batch(self, points: np.ndarray, derivative_order=None, *,
+                              derivative_id=None) -> np.ndarray:
+        """Reference ``vectorized_eval_batch`` (barycentric.py:992-1047): ``points`` of shape
+        ``(N, num_dimensions)`` -> ``(N,)`` float64.  One derivative transform (cached on
+        the device per spec) + one fused weights/contraction kernel."""
+        derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        return self._eval_points(points, derivative_order)
+
+    def vectorized_eval_multi(self, point, derivative_orders) -> List[float]:
+        """Reference ``vectorized_eval_multi`` (barycentric.py:1049-1112): several derivative
+        specs at one point."""
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        out = self.vectorized_eval_multi_batch(np.asarray([point], dtype=float), derivative_orders)
+        return [float(v) for v in out[0]]
+
+    def vectorized_eval_multi_batch(self, points: np.ndarray, derivative_orders) -> np.ndarray:
+        """Batched ``vectorized_eval_multi``: ``(N, d)`` points x ``m`` specs -> ``(N, m)``.
+        (Extension: the reference has no batched form; price + Greeks in one call.)"""
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        m = self._model()
+        pts = _lib.f64(points)
+        if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
+            raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
+        specs = _lib.i32(np.asarray(derivative_orders).reshape(-1, self.num_dimensions))
+        out = np.empty((pts.shape[0], specs.shape[0]))
+        _lib.check(m.lib.pcx_bary_eval_multi_batch(m.handle, _lib.p_f64(pts), pts.shape[0],
+                                                   _lib.p_i32(specs), specs.shape[0],
+                                                   _lib.p_f64(out)), m.lib)
+        return out
+
+    # aliases for the words BASELINE.json uses; the reference names above stay primary
+    def evaluate(self, points, derivative_order=None) -> np.ndarray:
+        order = [0] * self.num_dimensions if derivative_order is None else derivative_order
+        return self.vectorized_eval_batch(np.atleast_2d(np.asarray(points, dtype=float)), order)
+
+    def derivative(self, points, derivative_order) -> np.ndarray:
+        return self.vectorized_eval_batch(np.atleast_2d(np.asarray(points, dtype=float)), derivative_order)
+
+    # ---------------------------------------------------------------- derivative ids
+    def get_derivative_id(self, derivative_order) -> int:
+        """Reference barycentric.py:1173-1217."""
+        if len(derivative_order) != self.num_dimensions:
+            raise ValueError(f"derivative_order length {len(derivative_order)} does not "
+                             f"match num_dimensions {self.num_dimensions}")
+        for d, o in enumerate(derivative_order):
+            if not isinstance(o, (int, np.integer)):
+                raise ValueError(f"derivative_order[{d}] must be int, got {type(o).__name__}")
+            if o < 0 or o > self.max_derivative_order:
+                raise ValueError(f"derivative_order[{d}]={o} out of range [0, {self.max_derivative_order}]")
+        key = tuple(int(o) for o in derivative_order)
+        found = self._derivative_id_registry.get(key)
+        if found is not None:
+            return found
+        new_id = len(self._derivative_id_to_orders)
+        self._derivative_id_registry[key] = new_id
+        self._derivative_id_to_orders.append(key)
+        return new_id
+
+    def _resolve_derivative_args(self, derivative_order, derivative_id):
+        """Orders xor id (reference barycentric.py:1219-1243)."""
+        if derivative_order is not None and derivative_id is not None:
+            raise ValueError("provide exactly one of derivative_order or derivative_id, not both")
+        if derivative_order is None and derivative_id is None:
+            raise ValueError("must provide derivative_order or derivative_id")
+        if derivative_id is not None:
+            if derivative_id < 0 or derivative_id >= len(self._derivative_id_to_orders):
+                raise KeyError(f"unknown derivative_id {derivative_id}; register via get_derivative_id() first")
+            return list(self._derivative_id_to_orders[derivative_id])
+        return derivative_order
+
+    # ---------------------------------------------------------------- small getters
+    def is_construction_finished(self) -> bool:
+        return self.tensor_values is not None
+
+    def get_constructor_type(self) -> str:
+        return type(self).__name__
+
+    def get_used_ns(self) -> list:
+        return list(self.n_nodes)
+
+    def set_descriptor(self, descriptor: str) -> None:
+        if not isinstance(descriptor, str):
+            raise TypeError(f"descriptor must be str, got {type(descriptor).__name__}")
+        self.descriptor = descriptor
+
+    def get_descriptor(self) -> str:
+        return self.descriptor
+
+    def get_max_derivative_order(self) -> int:
+        return self.max_derivative_order
+
+    @staticmethod
+    def is_dimensionality_allowed(num_dimensions: int) -> bool:
+        return isinstance(num_dimensions, int) and num_dimensions >= 1
+
+    def get_special_points(self):
+        return self.special_points
+
+    def get_evaluation_points(self) -> np.ndarray:
+        """Full Cartesian grid, C-order rows (as ``nodes()['full_grid']``)."""
+        grids = np.meshgrid(*self.nodes, indexing="ij")
+        return np.column_stack([g.ravel() for g in grids])
+
+    # ---------------------------------------------------------------- factories
+    @staticmethod
+    def nodes(num_dimensions: int, domain, n_nodes) -> dict:
+        """Grid without function evaluation (reference barycentric.py:1700-1761)."""
+        if len(domain) != num_dimensions or len(n_nodes) != num_dimensions:
+            raise ValueError(f"len(domain)={len(domain)} and len(n_nodes)={len(n_nodes)} "
+                             f"must both equal num_dimensions={num_dimensions}")
+        per_dim = [chebyshev_nodes(lo, hi, n) for (lo, hi), n in zip(domain, n_nodes)]
+        grids = np.meshgrid(*per_dim, indexing="ij")
+        return {"nodes_per_dim": per_dim,
+                "full_grid": np.column_stack([g.ravel() for g in grids]),
+                "shape": tuple(n_nodes)}
+
+    @classmethod
+    def from_values(cls, tensor_values, num_dimensions: int, domain, n_nodes,
+                    max_derivative_order: int = 2) -> "ChebyshevApproximation":
+        """Interpolant from pre-computed grid values (reference barycentric.py:1813-1934)."""
+        tensor_values = np.asarray(tensor_values, dtype=float)
+        if len(domain) != num_dimensions or len(n_nodes) != num_dimensions:
+            raise ValueError(f"len(domain)={len(domain)} and len(n_nodes)={len(n_nodes)} "
+                             f"must both equal num_dimensions={num_dimensions}")
+        if tensor_values.shape != tuple(n_nodes):
+            raise ValueError(f"tensor_values.shape={tensor_values.shape} does not match "
+                             f"n_nodes={tuple(n_nodes)}")
+        if not np.isfinite(tensor_values).all():
+            raise ValueError("tensor_values contains NaN or Inf")
+        for d, (lo, hi) in enumerate(domain):
+            if lo >= hi:
+                raise ValueError(f"domain[{d}]: lo={lo} must be strictly less than hi={hi}")
+        obj = object.__new__(cls)
+        obj.function = None
+        obj.num_dimensions = num_dimensions
+        obj.domain = [list(b) for b in domain]
+        obj.n_nodes = list(n_nodes)
+        obj._original_n_nodes = list(n_nodes)
+        obj.max_derivative_order = max_derivative_order
+        obj.error_threshold = None
+        obj.max_n = 64
+        obj.tensor_values = tensor_values.copy()
+        obj._init_grid_metadata()
+        obj.build_time = 0.0
+        obj.n_evaluations = 0
+        obj._cached_error_estimate = None
+        obj.special_points = None
+        obj.descriptor = ""
+        obj.additional_data = None
+        obj.n_workers = None
+        obj._derivative_id_registry = {}
+        obj._derivative_id_to_orders = []
+        obj._device_model = None
+        obj._device_index = None
+        return obj
+
+    # ---------------------------------------------------------------- persistence
+    def __getstate__(self) -> dict:
+        """Pickle state without the callable and without the device handle
+        (reference barycentric.py:1523-1531)."""
+        state = self.__dict__.copy()
+        state["function"] = None
+        state.pop("_device_model", None)
+        state.pop("_device_index", None)
+        state["_pychebyshev_version"] = __version__
+        return state
+
+    def __setstate__(self, state: dict) -> None:
+        saved = state.pop("_pychebyshev_version", None)
+        if saved is not None and saved != __version__:
+            warnings.warn(f"This object was saved with pychebyshev {saved}, but you are loading it "
+                          f"with {__version__}. Evaluation results may differ if internal data "
+                          f"layout changed.", UserWarning, stacklevel=2)
+        state.pop("_eval_cache", None)
+        self.__dict__.update(state)
+        self.function = None
+        defaults = {"_cached_error_estimate": None, "descriptor": "", "additional_data": None,
+                    "_derivative_id_registry": {}, "_derivative_id_to_orders": [],
+                    "special_points": None, "n_workers": None, "error_threshold": None, "max_n": 64}
+        for key, val in defaults.items():
+            if not hasattr(self, key):
+                setattr(self, key, val)
+        if not hasattr(self, "_original_n_nodes"):
+            self._original_n_nodes = list(self.n_nodes)
+        self._device_model = None
+        self._device_index = None
+
+    def save(self, path, format: str = "pickle") -> None:
+        """Pickle persistence (reference barycentric.py:1576-1625).  ``format='binary'``
+        (.pcb) is the next row of the build plan and not implemented yet."""
+        if self.tensor_values is None:
+            raise RuntimeError("Cannot save an unbuilt ChebyshevApproximation. Call build() first.")
+        if format == "pickle":
+            with open(path, "wb") as f:
+                pickle.dump(self, f, protocol=pickle.HIGHEST_PROTOCOL)
+        elif format == "binary":
+            raise NotImplementedError(".pcb binary persistence is not implemented in this build yet")
+        else:
+            raise ValueError(f"format must be 'pickle' or 'binary', got {format!r}")
+
+    @classmethod
+    def load(cls, path) -> "ChebyshevApproximation":
+        with open(path, "rb") as f:
+            head = f.read(4)
+        if head == b"PCB\x00":
+            raise NotImplementedError(".pcb binary persistence is not implemented in this build yet")
+        with open(path, "rb") as f:
+            obj = pickle.load(f)  # noqa: S301 - same trust model as the reference
+        if not isinstance(obj, cls):
+            raise TypeError(f"Expected a {cls.__name__} instance, got {type(obj).__name__}")
+        return obj
+
+    # ---------------------------------------------------------------- printing
+    def __repr__(self) -> str:
+        return (f"ChebyshevApproximation(dims={self.num_dimensions}, nodes={self.n_nodes}, "
+                f"built={self.tensor_values is not None})")

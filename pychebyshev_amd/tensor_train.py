@@ -1,0 +1,595 @@
+"""``ChebyshevTT`` -- Chebyshev interpolant in tensor-train format, evaluated and built
+with MI355X kernels through ``libpcx_hip.so``.
+
+Host-side mirror of the reference class (``/root/reference/src/pychebyshev/tensor_train.py``,
+v0.21.1) for the hot path:
+
+    build(method="cross") -> _tt_cross                    (:1140-1289, :123-540)
+    eval / eval_batch / eval_multi (+ finite differences)  (:2127-2463)
+    tt_ranks / compression_ratio / total_build_evals / dim_order, pickle, repr
+
+Division of labour in the TT-Cross build: the Python callback, the evaluation cache,
+the NumPy RNG draws (their order defines the result for a given seed) and the index-set
+bookkeeping stay on the host, as in the reference; every dense step -- SVD-rank,
+maxvol, ``U inv(U[piv])``, the TT chain of the convergence check and the value->coefficient
+DCT -- runs on the device (``pcx_tt_cross_step``, ``pcx_tt_grid_eval``,
+``pcx_tt_value_to_coeff_core``).  Evaluation (single, batch, finite-difference stencils)
+is always a ``pcx_tt_eval_batch`` launch; there is no CPU fallback.
+
+Out of scope in this tier (raise ``NotImplementedError``): ``method='svd'`` / ``'als'``
+builders, algebra, calculus, slicing, reordering, Sobol indices.
+"""
+from __future__ import annotations
+
+import ctypes
+import pickle
+import time
+import warnings
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+from numpy.polynomial.chebyshev import chebpts1
+
+from . import _lib
+from ._version import __version__
+
+__all__ = ["ChebyshevTT"]
+
+
+# --------------------------------------------------------------------------------------
+# device-backed dense steps
+# --------------------------------------------------------------------------------------
+
+def _device() -> int:
+    return _lib.default_device()
+
+
+def _cross_step(C: np.ndarray, cap: int, rel_thresh: float = 1e-12):
+    """SVD-rank + maxvol + cross interpolation of one unfolding on the device
+    (reference tensor_train.py:332-362).  Returns (C_hat (m, rank), pivots (rank,), rank)."""
+    lib = _lib.load()
+    C = _lib.f64(C)
+    m, c = C.shape
+    chat = np.empty(m * c)
+    piv = np.zeros(c, dtype=np.int64)
+    rank = ctypes.c_int32(0)
+    _lib.check(lib.pcx_tt_cross_step(_device(), _lib.p_f64(C), m, c, int(cap), float(rel_thresh),
+                                     _lib.p_f64(chat), _lib.p_i64(piv), ctypes.byref(rank)), lib)
+    r = int(rank.value)
+    return chat[: m * r].reshape(m, r).copy(), piv[:r].astype(np.intp), r
+
+
+def _maxvol(A: np.ndarray, tol: float = 1.05, max_iters: int = 100) -> np.ndarray:
+    """Rows of an (m, r) matrix with approximately maximal volume
+    (reference tensor_train.py:38-120), computed on the device."""
+    lib = _lib.load()
+    A = _lib.f64(A)
+    m, r = A.shape
+    idx = np.zeros(min(m, r) if m <= r else r, dtype=np.int64)
+    _lib.check(lib.pcx_maxvol(_device(), _lib.p_f64(A), m, r, float(tol), int(max_iters),
+                              _lib.p_i64(idx)), lib)
+    return idx.astype(np.intp)
+
+
+def _value_core_to_coeff_core(value_core: np.ndarray) -> np.ndarray:
+    """Values at type-I nodes -> Chebyshev coefficients along axis 1
+    (reference tensor_train.py:997-1016), DCT-II evaluated on the device."""
+    lib = _lib.load()
+    vc = _lib.f64(value_core)
+    rl, n, rr = vc.shape
+    out = np.empty_like(vc)
+    _lib.check(lib.pcx_tt_value_to_coeff_core(_device(), _lib.p_f64(vc), rl, n, rr,
+                                              _lib.p_f64(out)), lib)
+    return out
+
+
+def _tt_grid_values(cores: Sequence[np.ndarray], idx: np.ndarray) -> np.ndarray:
+    """TT value at integer grid index tuples through the chain of value cores
+    (reference ``_eval_tt``, tensor_train.py:223-228), batched on the device."""
+    lib = _lib.load()
+    d = len(cores)
+    n = _lib.i32([c.shape[1] for c in cores])
+    ranks = _lib.i32([1] + [c.shape[2] for c in cores])
+    cat = _lib.f64(np.concatenate([np.asarray(c, dtype=float).ravel() for c in cores]))
+    ii = _lib.i32(idx).reshape(-1, d)
+    out = np.empty(ii.shape[0])
+    _lib.check(lib.pcx_tt_grid_eval(_device(), d, _lib.p_i32(n), _lib.p_i32(ranks), _lib.p_f64(cat),
+                                    _lib.p_i32(ii), ii.shape[0], _lib.p_f64(out)), lib)
+    return out
+
+
+# --------------------------------------------------------------------------------------
+# TT-Cross (host orchestration; reference tensor_train.py:123-540)
+# --------------------------------------------------------------------------------------
+
+class _CrossBuilder:
+    """Alternating left-to-right / right-to-left cross approximation with maxvol pivots.
+
+    State: left/right multi-index sets per dimension, the evaluation cache, the best cores
+    seen so far.  The RNG is drawn in the reference's order: first the right index sets
+    (one ``integers`` call per column, :252-263), then one call per dimension for every
+    convergence check (:289-291).
+    """
+
+    def __init__(self, func: Callable, grids: List[np.ndarray], max_rank: int, tol: float,
+                 max_sweeps: int, verbose, seed):
+        self.func = func
+        self.grids = grids
+        self.d = len(grids)
+        self.n = [len(g) for g in grids]
+        self.tol = tol
+        self.max_sweeps = max_sweeps
+        self.verbose = verbose
+        self.rng = np.random.default_rng(seed)
+        self.cache: dict = {}
+        d, n = self.d, self.n
+        self.caps = [1] * (d + 1)
+        for k in range(1, d):
+            self.caps[k] = min(max_rank, int(np.prod(n[:k])), int(np.prod(n[k:])))
+        start_rank = [1] * (d + 1)
+        for k in range(1, d):
+            start_rank[k] = min(self.caps[k], n[k - 1], n[k])
+        self.right = [None] * d
+        for k in range(d - 1):
+            cols = [self.rng.integers(0, n[k + 1 + j], size=start_rank[k + 1]) for j in range(d - k - 1)]
+            self.right[k] = np.column_stack(cols)
+        self.right[d - 1] = np.zeros((1, 0), dtype=np.intp)
+        self.left = [None] * d
+        self.left[0] = np.zeros((1, 0), dtype=np.intp)
+        self.cores = [None] * d
+        self.n_test = min(20, max(5, d))
+        self.best_err = float("inf")
+        self.best_cores = None
+        self.stale = 0
+
+    # -- function values through the cache (key = grid index tuple, :215-221)
+    def value(self, index) -> float:
+        key = tuple(int(i) for i in index)
+        hit = self.cache.get(key)
+        if hit is None:
+            hit = self.func([float(self.grids[k][key[k]]) for k in range(self.d)], None)
+            self.cache[key] = hit
+        return hit
+
+    def unfolding(self, k: int) -> np.ndarray:
+        """Values f(left[a], i, right[b]) as an array of shape (r_left, n_k, r_right)."""
+        L, R = self.left[k], self.right[k]
+        out = np.empty((L.shape[0], self.n[k], R.shape[0]))
+        for a, lrow in enumerate(L):
+            head = list(lrow)
+            for i in range(self.n[k]):
+                mid = head + [i]
+                for b, rrow in enumerate(R):
+                    out[a, i, b] = self.value(mid + list(rrow))
+        return out
+
+    def check(self) -> float:
+        """Relative error of the TT at n_test random grid points (:287-297)."""
+        pts = np.column_stack([self.rng.integers(0, self.n[k], size=self.n_test) for k in range(self.d)])
+        approx = _tt_grid_values(self.cores, pts)
+        exact = np.array([self.value(p) for p in pts])
+        ref = np.linalg.norm(exact)
+        err = np.linalg.norm(approx - exact)
+        return float(err / ref) if ref > 0 else float(err)
+
+    def note(self, err: float, label: str) -> bool:
+        """Best-cores bookkeeping and stop rules (:403-422, :515-534).  True = stop."""
+        if err < self.best_err * 0.9:
+            self.best_err = err
+            self.best_cores = [c.copy() for c in self.cores]
+            self.stale = 0
+        else:
+            self.stale += 1
+        if err < self.tol:
+            if self.verbose:
+                print(f"    Converged after {label}")
+            return True
+        if self.stale >= 3 and self.best_err < 1e-3:
+            if self.verbose:
+                print(f"    No improvement in {self.stale} checks (best = {self.best_err:.2e}) — stopping")
+            return True
+        return False
+
+    def sweep_left_to_right(self) -> None:
+        d, n = self.d, self.n
+        for k in range(d - 1):
+            T = self.unfolding(k)
+            rl, nk, rr = T.shape
+            chat, piv, rank = _cross_step(T.reshape(rl * nk, rr), self.caps[k + 1])
+            self.cores[k] = chat.reshape(rl, nk, rank)
+            new_left = np.empty((rank, k + 1), dtype=np.intp)
+            for t, p in enumerate(piv):
+                a, ik = divmod(int(p), nk)
+                a = min(a, rl - 1)
+                new_left[t, :k] = self.left[k][a]
+                new_left[t, k] = ik
+            self.left[k + 1] = new_left
+        T = self.unfolding(d - 1)          # right set is the empty tuple: shape (r, n, 1)
+        self.cores[d - 1] = T.reshape(T.shape[0], n[d - 1], 1).copy()
+
+    def sweep_right_to_left(self) -> None:
+        d, n = self.d, self.n
+        for k in range(d - 1, 0, -1):
+            T = self.unfolding(k)
+            rl, nk, rr = T.shape
+            Ct = T.reshape(rl, nk * rr).T                    # rows = (node, right index)
+            chat_t, piv, rank = _cross_step(np.ascontiguousarray(Ct), self.caps[k])
+            self.cores[k] = chat_t.T.reshape(rank, nk, rr).copy()
+            new_right = np.empty((rank, d - k), dtype=np.intp)
+            span = max(rr, 1)
+            for t, p in enumerate(piv):
+                ik, b = divmod(int(p), span)
+                ik = min(ik, nk - 1)
+                b = min(b, span - 1)
+                new_right[t, 0] = ik
+                new_right[t, 1:] = self.right[k][b]
+            self.right[k - 1] = new_right
+        T = self.unfolding(0)              # left set is the empty tuple: shape (1, n, r)
+        self.cores[0] = T.copy()
+
+    def run(self):
+        for sweep in range(self.max_sweeps):
+            self.sweep_left_to_right()
+            err = self.check()
+            if self.verbose:
+                ranks = [1] + [c.shape[2] for c in self.cores]
+                print(f"    Sweep {sweep + 1} L->R: rel error = {err:.2e}, "
+                      f"unique evals = {len(self.cache):,}, ranks = {ranks}")
+            if self.note(err, f"{sweep + 1} sweeps (L->R)"):
+                break
+            self.sweep_right_to_left()
+            err = self.check()
+            if self.verbose:
+                print(f"    Sweep {sweep + 1} R->L: rel error = {err:.2e}, "
+                      f"unique evals = {len(self.cache):,}")
+            if self.note(err, f"{sweep + 1} sweeps"):
+                break
+        cores = self.best_cores if self.best_cores is not None else self.cores
+        return cores, len(self.cache)
+
+
+def _tt_cross(func, grids, max_rank, tol, max_sweeps, verbose, seed=None):
+    """TT value cores from a callable via alternating TT-Cross (reference :123-540)."""
+    return _CrossBuilder(func, grids, max_rank, tol, max_sweeps, verbose, seed).run()
+
+
+# --------------------------------------------------------------------------------------
+# ChebyshevTT
+# --------------------------------------------------------------------------------------
+
+class _DeviceTT:
+    """Owner of one ``pcx_tt`` handle (freed on garbage collection)."""
+
+    def __init__(self, tt: "ChebyshevTT", device: int):
+        lib = _lib.load()
+        cores = tt._coeff_cores
+        d = tt.num_dimensions
+        n = _lib.i32([c.shape[1] for c in cores])
+        ranks = _lib.i32([cores[0].shape[0]] + [c.shape[2] for c in cores])
+        lo = _lib.f64([float(b[0]) for b in tt.domain])
+        hi = _lib.f64([float(b[1]) for b in tt.domain])
+        cat = _lib.f64(np.concatenate([np.asarray(c, dtype=float).ravel() for c in cores]))
+        order = _lib.i32(tt._dim_order)
+        handle = ctypes.c_void_p()
+        _lib.check(lib.pcx_tt_create(device, d, _lib.p_i32(n), _lib.p_i32(ranks), _lib.p_f64(lo),
+                                     _lib.p_f64(hi), _lib.p_f64(cat), _lib.p_i32(order),
+                                     ctypes.byref(handle)), lib)
+        self.lib = lib
+        self.handle = handle
+        self.device = device
+        self.key = (id(cores), tuple(id(c) for c in cores), tuple(tt._dim_order))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pcx_tt_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class ChebyshevTT:
+    """Chebyshev interpolation in tensor-train format (signature: reference :1088-1100)."""
+
+    def __init__(self, function: Callable, num_dimensions: int,
+                 domain: Sequence[Tuple[float, float]], n_nodes: Sequence[int], max_rank: int = 10,
+                 tolerance: float = 1e-6, max_sweeps: int = 10, additional_data: object = None, *,
+                 max_derivative_order: int = 2):
+        from . import Domain, Ns
+        if isinstance(domain, Domain):
+            domain = list(domain.bounds)
+        if isinstance(n_nodes, Ns):
+            n_nodes = list(n_nodes.counts)
+        if len(domain) != num_dimensions:
+            raise ValueError(f"domain has {len(domain)} entries but num_dimensions={num_dimensions}")
+        if len(n_nodes) != num_dimensions:
+            raise ValueError(f"n_nodes has {len(n_nodes)} entries but num_dimensions={num_dimensions}")
+        self.function = function
+        self.num_dimensions = num_dimensions
+        self.domain = domain
+        self.n_nodes = n_nodes
+        self.max_rank = max_rank
+        self.tolerance = tolerance
+        self.max_sweeps = max_sweeps
+        self.max_derivative_order = max_derivative_order
+        self._coeff_cores: List[np.ndarray] | None = None
+        self._built = False
+        self.descriptor = ""
+        self.additional_data = additional_data
+        self._tt_ranks: List[int] | None = None
+        self._build_time = 0.0
+        self._total_build_evals = 0
+        self._cached_error_estimate = None
+        self.method: str | None = None
+        self._dim_order: List[int] = list(range(num_dimensions))
+        self._device_tt: _DeviceTT | None = None
+        self._device_index: int | None = None
+
+    # ---------------------------------------------------------------- build
+    def build(self, verbose: bool | int = True, seed: int | None = None, method: str = "cross") -> None:
+        """TT-Cross build then value->coefficient conversion (reference :1140-1289)."""
+        if method not in ("cross", "svd", "als"):
+            raise ValueError(f"method must be 'cross', 'svd', or 'als', got {method!r}")
+        if method != "cross":
+            raise NotImplementedError(f"method={method!r} builds the full tensor on the host with "
+                                      "LAPACK in the reference; only 'cross' is in this build's scope")
+        self.method = method
+        start = time.time()
+        self._cached_error_estimate = None
+        full = int(np.prod(self.n_nodes))
+        if verbose:
+            print(f"Building {self.num_dimensions}D ChebyshevTT (max_rank={self.max_rank}, method={method!r})...")
+            print(f"  Full tensor would need {full:,} evaluations")
+        grids = [np.sort(0.5 * (a + b) + 0.5 * (b - a) * chebpts1(n))
+                 for (a, b), n in zip(self.domain, self.n_nodes)]
+        data, raw = self.additional_data, self.function
+
+        def with_data(point, _unused):
+            return raw(point, data)
+
+        if verbose:
+            print("  Running TT-Cross...")
+        value_cores, n_evals = _tt_cross(with_data, grids, self.max_rank, self.tolerance,
+                                         self.max_sweeps, verbose, seed)
+        self._total_build_evals = n_evals
+        self._coeff_cores = [_value_core_to_coeff_core(c) for c in value_cores]
+        self._tt_ranks = [1] + [c.shape[2] for c in self._coeff_cores]
+        self._build_time = time.time() - start
+        self._built = True
+        self._device_tt = None
+        if verbose:
+            storage = sum(c.size for c in self._coeff_cores)
+            print(f"  Built in {self._build_time:.3f}s ({n_evals:,} function evaluations)")
+            print(f"  TT ranks: {self._tt_ranks}")
+            print(f"  Compression: {full:,} -> {storage:,} elements ({full / storage:.1f}x)")
+
+    @classmethod
+    def from_coeff_cores(cls, coeff_cores: Sequence[np.ndarray], domain, dim_order=None,
+                         max_derivative_order: int = 2) -> "ChebyshevTT":
+        """Wrap existing Chebyshev coefficient cores ``(r_{k-1}, n_k, r_k)`` (extension; the
+        reference builds such objects through its ``object.__new__`` factory pattern, :2946-2965)."""
+        cores = [np.array(c, dtype=float) for c in coeff_cores]
+        d = len(cores)
+        obj = cls(None, d, [list(b) for b in domain], [c.shape[1] for c in cores],
+                  max_rank=max(c.shape[2] for c in cores), max_derivative_order=max_derivative_order)
+        for k in range(d - 1):
+            if cores[k].shape[2] != cores[k + 1].shape[0]:
+                raise ValueError(f"core {k} right rank {cores[k].shape[2]} != core {k + 1} left rank {cores[k + 1].shape[0]}")
+        if cores[0].shape[0] != 1 or cores[-1].shape[2] != 1:
+            raise ValueError("boundary TT ranks must be 1")
+        obj._coeff_cores = cores
+        obj._tt_ranks = [1] + [c.shape[2] for c in cores]
+        obj._built = True
+        obj.method = "cross"
+        if dim_order is not None:
+            if sorted(dim_order) != list(range(d)):
+                raise ValueError("dim_order must be a permutation of range(num_dimensions)")
+            obj._dim_order = [int(v) for v in dim_order]
+        return obj
+
+    def _check_built(self) -> None:
+        if not self._built:
+            raise RuntimeError("Call build() before using this method.")
+
+    # ---------------------------------------------------------------- device plumbing
+    def to_device(self, device: int | None = None) -> "ChebyshevTT":
+        self._check_built()
+        dev = _lib.default_device() if device is None else int(device)
+        self._device_index = dev
+        self._device_tt = _DeviceTT(self, dev)
+        return self
+
+    def invalidate_device_cache(self) -> None:
+        self._device_tt = None
+
+    def _dev(self) -> _DeviceTT:
+        t = self._device_tt
+        key = (id(self._coeff_cores), tuple(id(c) for c in self._coeff_cores), tuple(self._dim_order))
+        if t is None or t.key != key:
+            self.to_device(self._device_index)
+            t = self._device_tt
+        return t
+
+    def _eval_user_points(self, pts: np.ndarray) -> np.ndarray:
+        """Points in the USER's dimension order; the device applies ``_dim_order``."""
+        t = self._dev()
+        pts = _lib.f64(pts)
+        if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
+            raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
+        out = np.empty(pts.shape[0])
+        _lib.check(t.lib.pcx_tt_eval_batch(t.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_f64(out)), t.lib)
+        return out
+
+    def _storage_to_user(self, pts_storage: np.ndarray) -> np.ndarray:
+        """Rows in storage frame -> rows in user frame (inverse of points[:, _dim_order])."""
+        if self._dim_order == list(range(self.num_dimensions)):
+            return pts_storage
+        out = np.empty_like(pts_storage)
+        out[:, self._dim_order] = pts_storage
+        return out
+
+    # ---------------------------------------------------------------- evaluation API
+    def eval(self, point) -> float:
+        """Value at one point (reference :2127-2170)."""
+        self._check_built()
+        return float(self._eval_user_points(np.asarray([list(point)], dtype=float))[0])
+
+    def eval_batch(self, points) -> np.ndarray:
+        """Values at ``(N, num_dimensions)`` points (reference :2217-2265)."""
+        self._check_built()
+        return self._eval_user_points(np.asarray(points))
+
+    def eval_multi(self, point, derivative_orders) -> List[float]:
+        """Value and central-finite-difference derivatives at one point (reference
+        :2267-2463).  All stencil points of all specs go to the device in ONE batch; the
+        stencil arithmetic (h = 1e-4 (b - a), boundary nudge 1.5 h, 2/3/4-point and nested
+        rules) is then replayed on the host in the reference's order."""
+        self._check_built()
+        d = self.num_dimensions
+        order = self._dim_order
+        if order != list(range(d)):
+            pt = [point[order[k]] for k in range(d)]
+            specs = [[s[order[k]] for k in range(d)] for s in derivative_orders]
+        else:
+            pt = list(point)
+            specs = [list(s) for s in derivative_orders]
+
+        pending: list = []
+
+        def run(value_of):
+            return [self._fd_spec(pt, spec, value_of) for spec in specs]
+
+        def record(p):
+            pending.append(list(p))
+            return 0.0
+
+        run(record)                                   # pass 1: collect stencil points
+        vals = self._eval_user_points(self._storage_to_user(np.asarray(pending, dtype=float)))
+        it = iter(vals)
+        return run(lambda p: float(next(it)))         # pass 2: same traversal, real values
+
+    # finite-difference rules, all in storage frame (reference :2322-2463)
+    def _fd_step(self, k: int) -> float:
+        a, b = self.domain[k]
+        return (b - a) * 1e-4
+
+    def _nudge(self, p, k: int, h: float):
+        p = list(p)
+        a, b = self.domain[k]
+        need = h * 1.5
+        if p[k] - a < need:
+            p[k] = a + need
+        if b - p[k] < need:
+            p[k] = b - need
+        return p
+
+    @staticmethod
+    def _moved(p, k, delta):
+        q = list(p)
+        q[k] += delta
+        return q
+
+    def _fd_nested(self, p, active, value_of):
+        if not active:
+            return value_of(p)
+        (k, o), rest = active[0], active[1:]
+        h = self._fd_step(k)
+        p = self._nudge(p, k, h)
+        if o == 1:
+            up = self._fd_nested(self._moved(p, k, h), rest, value_of)
+            dn = self._fd_nested(self._moved(p, k, -h), rest, value_of)
+            return (up - dn) / (2.0 * h)
+        if o == 2:
+            up = self._fd_nested(self._moved(p, k, h), rest, value_of)
+            mid = self._fd_nested(p, rest, value_of)
+            dn = self._fd_nested(self._moved(p, k, -h), rest, value_of)
+            return (up - 2.0 * mid + dn) / (h * h)
+        raise ValueError(f"Derivative order {o} not supported (use 1 or 2)")
+
+    def _fd_spec(self, pt, spec, value_of):
+        active = [(k, o) for k, o in enumerate(spec) if o > 0]
+        if len(active) == 2 and active[0][1] == 1 and active[1][1] == 1:
+            (k1, _), (k2, _) = active
+            h1, h2 = self._fd_step(k1), self._fd_step(k2)
+            p = self._nudge(self._nudge(pt, k1, h1), k2, h2)
+
+            def at(s1, s2):
+                q = list(p)
+                q[k1] += s1 * h1
+                q[k2] += s2 * h2
+                return value_of(q)
+            f_pp, f_pm, f_mp, f_mm = at(+1, +1), at(+1, -1), at(-1, +1), at(-1, -1)
+            return (f_pp - f_pm - f_mp + f_mm) / (4.0 * h1 * h2)
+        return self._fd_nested(pt, active, value_of)
+
+    # ---------------------------------------------------------------- properties
+    @property
+    def tt_ranks(self) -> List[int]:
+        self._check_built()
+        return list(self._tt_ranks)
+
+    @property
+    def compression_ratio(self) -> float:
+        self._check_built()
+        return int(np.prod(self.n_nodes)) / sum(c.size for c in self._coeff_cores)
+
+    @property
+    def total_build_evals(self) -> int:
+        return self._total_build_evals
+
+    @property
+    def dim_order(self) -> List[int]:
+        return list(self._dim_order)
+
+    def is_construction_finished(self) -> bool:
+        return self._built
+
+    def error_estimate(self) -> float:
+        """Sum over dimensions of the largest last Chebyshev coefficient (reference :2469-2504)."""
+        self._check_built()
+        if self._cached_error_estimate is None:
+            self._cached_error_estimate = float(sum(np.max(np.abs(c[:, -1, :])) for c in self._coeff_cores))
+        return self._cached_error_estimate
+
+    # ---------------------------------------------------------------- persistence
+    def __getstate__(self) -> dict:
+        state = self.__dict__.copy()
+        state["function"] = None
+        state.pop("_device_tt", None)
+        state.pop("_device_index", None)
+        state["_pychebyshev_version"] = __version__
+        return state
+
+    def __setstate__(self, state: dict) -> None:
+        saved = state.pop("_pychebyshev_version", None)
+        if saved is not None and saved != __version__:
+            warnings.warn(f"This object was saved with pychebyshev {saved}, but you are loading it "
+                          f"with {__version__}. Evaluation results may differ if internal data "
+                          f"layout changed.", UserWarning, stacklevel=2)
+        self.__dict__.update(state)
+        self.function = None
+        for key, val in (("_cached_error_estimate", None), ("additional_data", None),
+                         ("descriptor", ""), ("max_derivative_order", 2)):
+            if not hasattr(self, key):
+                setattr(self, key, val)
+        if not hasattr(self, "_dim_order"):
+            self._dim_order = list(range(self.num_dimensions))
+        self._device_tt = None
+        self._device_index = None
+
+    def save(self, path) -> None:
+        self._check_built()
+        with open(path, "wb") as f:
+            pickle.dump(self, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    @classmethod
+    def load(cls, path) -> "ChebyshevTT":
+        with open(path, "rb") as f:
+            obj = pickle.load(f)  # noqa: S301 - same trust model as the reference
+        if not isinstance(obj, cls):
+            raise TypeError(f"Expected a {cls.__name__} instance, got {type(obj).__name__}")
+        return obj
+
+    def __repr__(self) -> str:
+        return (f"ChebyshevTT(dims={self.num_dimensions}, nodes={self.n_nodes}, "
+                f"max_rank={self.max_rank}, built={self._built})")

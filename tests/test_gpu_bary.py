@@ -1,0 +1,313 @@
+"""GPU parity tests for the barycentric path: the HIP kernels (through the C ABI and the
+Python classes) against the reference's golden vectors, against the CPU oracle on seeded
+inputs, and -- at BASELINE.json's full batch sizes -- through size-independent properties.
+
+Tolerances: north_star's 1e-12 relative, measured normwise; value specs
+additionally pointwise on |ref| >= 1e-3 max|ref| (see conftest.spec_point_tol)."""
+import ctypes
+import struct
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_parity, golden, parity, spec_point_tol
+import functions as F
+
+from pychebyshev_amd import ChebyshevApproximation, _lib
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def bs5d():
+    g = golden("g2_bs5d")
+    return ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES), g
+
+
+def _set_kernel(c, variant):
+    m = c._model()
+    _lib.check(m.lib.pcx_bary_set_kernel(m.handle, variant), m.lib)
+
+
+def _oracle_model(o, c):
+    return o.BaryModel(c.nodes, c.weights, c.diff_matrices, c.tensor_values)
+
+
+# ------------------------------------------------------------------ golden vectors
+def test_config1_sincos_2d_built_through_callback():
+    g = golden("g1_sincos2d")
+    c = ChebyshevApproximation(F.sin_cos_2d, 2, [[-1, 1], [-1, 1]], [12, 12])
+    c.build(verbose=False)
+    assert np.array_equal(c.tensor_values, g["tensor"])
+    pts = np.random.default_rng(int(g["seed"])).uniform(-1, 1, (10_000, 2))
+    for variant in (2, 1):
+        _set_kernel(c, variant)
+        for s, ref in zip(g["specs"], g["out"]):
+            assert_parity(c.vectorized_eval_batch(pts, list(s)), ref, 1e-12, f"g1 v{variant} {s}",
+                          spec_point_tol(s))
+    # true function: reference's own accuracy claim for n=12 (max abs err ~1e-12)
+    _set_kernel(c, 0)
+    y = c.vectorized_eval_batch(pts, [0, 0])
+    assert np.max(np.abs(y - np.sin(pts[:, 0]) * np.cos(pts[:, 1]))) < 5e-12
+
+
+@pytest.mark.parametrize("variant", [2, 1])
+def test_bs5d_value_and_greeks_match_reference(bs5d, variant):
+    c, g = bs5d
+    _set_kernel(c, variant)
+    try:
+        for s, ref in zip(g["specs"], g["out"]):
+            y = c.vectorized_eval_batch(g["points"], list(s))
+            assert_parity(y, ref, 1e-12, f"g2 v{variant} {s}", spec_point_tol(s))
+        # every coordinate on a node: tensor entries come back bit-for-bit
+        y0 = c.vectorized_eval_batch(g["points"][4352:4384], [0] * 5)
+        assert np.array_equal(y0, g["out"][0][4352:4384])
+    finally:
+        _set_kernel(c, 0)
+
+
+def test_bs5d_multi_single_and_scalar_siblings(bs5d):
+    c, g = bs5d
+    specs = g["specs"].tolist()
+    idx = g["multi_idx"]
+    got = c.vectorized_eval_multi_batch(g["points"][idx], specs)
+    for col in range(len(specs)):
+        scale = np.max(np.abs(g["out"][col]))
+        assert np.max(np.abs(got[:, col] - g["multi"][:, col])) <= 1e-12 * scale
+    one = c.vectorized_eval_multi(list(g["points"][idx[3]]), specs)
+    assert isinstance(one, list) and np.array_equal(one, got[3])
+    for r, i in enumerate(idx[:16]):
+        for col, s in enumerate(specs):
+            v = c.vectorized_eval(list(g["points"][i]), s)
+            assert abs(v - g["single"][r, col]) <= 1e-12 * np.max(np.abs(g["out"][col]))
+    for r, i in enumerate(idx[:4]):
+        for col, s in enumerate(specs[:3]):
+            assert abs(c.eval(list(g["points"][i]), s) - g["scalar"][r, col]) <= 1e-12 * np.max(np.abs(g["out"][col]))
+    did = c.get_derivative_id([1, 0, 0, 0, 0])
+    assert np.array_equal(c.vectorized_eval_batch(g["points"][:64], derivative_id=did),
+                          c.vectorized_eval_batch(g["points"][:64], [1, 0, 0, 0, 0]))
+    # closed form: price < 0.01 %, delta/gamma within the reference's 1-3 % (test_barycentric.py:70-110)
+    p = np.array([[100.0, 100.0, 1.0, 0.25, 0.05]])
+    price, delta, gamma = c.vectorized_eval_multi_batch(p, specs[:3])[0]
+    assert abs(price / F.bs_call_price(100, 100, 1.0, 0.05, 0.25, F.BS_Q) - 1) < 1e-4
+    assert abs(delta / F.bs_call_delta(100, 100, 1.0, 0.05, 0.25, F.BS_Q) - 1) < 1e-2
+    assert abs(gamma / F.bs_call_gamma(100, 100, 1.0, 0.05, 0.25, F.BS_Q) - 1) < 3e-2
+
+
+def _read_pcb(path):
+    raw = open(path, "rb").read()
+    d = struct.unpack_from("<I", raw, 12)[0]
+    off = 16
+    lo = np.frombuffer(raw, "<f8", d, off); off += 8 * d
+    hi = np.frombuffer(raw, "<f8", d, off); off += 8 * d
+    n = np.frombuffer(raw, "<u4", d, off); off += 4 * d
+    T = np.frombuffer(raw, "<f8", int(np.prod(n)), off).reshape(tuple(int(v) for v in n))
+    return [[float(a), float(b)] for a, b in zip(lo, hi)], [int(v) for v in n], T
+
+
+def test_reference_pcb_fixtures():
+    g = golden("g3_pcb")
+    dom, n, T = _read_pcb(os.path.join(GOLDEN, "approx_5d_bs.pcb"))
+    c5 = ChebyshevApproximation.from_values(T, 5, dom, n)
+    assert_parity(c5.vectorized_eval_batch(g["p5"], [0] * 5), g["v5"], 1e-12, "pcb5 value")
+    assert_parity(c5.vectorized_eval_batch(g["p5"], [0, 1, 0, 0, 1]), g["d5"], 1e-12, "pcb5 deriv", float("inf"))
+    assert abs(c5.vectorized_eval([0.1, -0.2, 0.3, 0.4, -0.5], [0] * 5) - 0.969884514613979) < 1e-14
+    dom, n, T = _read_pcb(os.path.join(GOLDEN, "approx_2d_simple.pcb"))
+    c2 = ChebyshevApproximation.from_values(T, 2, dom, n)
+    assert_parity(c2.vectorized_eval_batch(g["p2"], [0, 0]), g["v2"], 1e-12, "pcb2 value")
+    assert_parity(c2.vectorized_eval_batch(g["p2"], [1, 1]), g["d2"], 1e-12, "pcb2 deriv", float("inf"))
+
+
+def test_small_and_odd_shapes_match_reference():
+    g = golden("g8_small_bary")
+    for tag in "abcde":
+        T = g[f"{tag}_tensor"]
+        dom = [list(b) for b in g[f"{tag}_domain"]]
+        c = ChebyshevApproximation.from_values(T, T.ndim, dom, list(T.shape))
+        inside = np.r_[0:10, 15:200]
+        for variant in (0, 1):
+            _set_kernel(c, variant)
+            for s, ref in zip(g[f"{tag}_specs"], g[f"{tag}_out"]):
+                y = c.vectorized_eval_batch(g[f"{tag}_points"], list(s))
+                assert_parity(y[inside], ref[inside], 1e-12, f"g8{tag} v{variant} {s}", spec_point_tol(s),
+                              floor=np.max(np.abs(T)))
+                assert np.allclose(y[10:15], ref[10:15], rtol=1e-7, atol=1e-9 * np.max(np.abs(T)))
+
+
+# ------------------------------------------------------------------ against the oracle
+def test_derivative_tensor_kernel_is_bit_identical_to_oracle(bs5d, oracle_mod):
+    """K3 (k_mode_product) and the oracle use the same j-ascending fma chain."""
+    c, g = bs5d
+    m = c._model()
+    o = oracle_mod
+    om = _oracle_model(o, c)
+    for spec in ([1, 0, 0, 0, 0], [2, 0, 0, 0, 0], [1, 0, 0, 1, 0], [0, 2, 1, 0, 1]):
+        got = np.empty(c.tensor_values.shape)
+        s = _lib.i32(spec)
+        _lib.check(m.lib.pcx_bary_derivative_tensor(m.handle, _lib.p_i32(s), _lib.p_f64(got)), m.lib)
+        lib = o._lib()
+        lib.pcxo_apply_derivative_passes.restype = ctypes.POINTER(ctypes.c_double)
+        ptr = lib.pcxo_apply_derivative_passes(ctypes.c_int(5), om.n.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+                                               om.diff_cat.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                               om.tensor.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                               s.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)))
+        want = np.ctypeslib.as_array(ptr, shape=(c.tensor_values.size,)).reshape(c.tensor_values.shape).copy()
+        ctypes.CDLL(None).free(ptr)
+        assert np.array_equal(got, want), spec
+
+
+@pytest.mark.parametrize("shape,dom", [
+    ((7,), [[-2.0, 5.0]]),
+    ((1, 9), [[0.0, 1.0], [-1.0, 1.0]]),
+    ((64, 3), [[0.0, 1.0], [-1.0, 1.0]]),
+    ((5, 6, 7), [[0, 1], [1, 2], [2, 3]]),
+    ((3, 4, 2, 5, 3, 2), [[-1, 1]] * 6),
+    ((2, 3, 2, 3, 2, 3, 2, 3), [[0, 1]] * 8),
+    ((2, 2, 2, 2, 2, 2, 2, 2, 2, 3), [[0, 1]] * 10),      # d = 10 > 8: rows kernel only
+    ((130, 2), [[0.0, 1.0], [0.0, 1.0]]),                  # last-dim n > 128 with K too large -> split picks head
+    ((2, 200), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 200 > 128: rows kernel
+])
+def test_random_shapes_against_oracle(oracle_mod, shape, dom):
+    rng = np.random.default_rng(sum(shape))
+    T = rng.standard_normal(shape)
+    d = len(shape)
+    c = ChebyshevApproximation.from_values(T, d, dom, list(shape))
+    pts = np.column_stack([rng.uniform(lo, hi, 777) for lo, hi in dom])
+    for k in range(d):                      # a few rows exactly on nodes
+        pts[k, k] = c.nodes[k][rng.integers(0, shape[k])]
+    om = _oracle_model(oracle_mod, c)
+    specs = [[0] * d]
+    if all(v > 2 for v in shape):
+        specs.append([1] + [0] * (d - 1))
+        specs.append([0] * (d - 1) + [2])
+    for s in specs:
+        ref = oracle_mod.bary_eval_batch(om, pts, s)
+        assert_parity(c.vectorized_eval_batch(pts, s), ref, 1e-12, f"{shape} {s}", spec_point_tol(s),
+                      floor=np.max(np.abs(T)))
+    info = _lib.i32(np.zeros(6))
+    m = c._model()
+    m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
+    if d > 8 or shape == (2, 200):
+        assert info[0] == 1, "expected the rows kernel for this shape"
+
+
+def test_edge_inputs(bs5d):
+    c, g = bs5d
+    assert c.vectorized_eval_batch(np.zeros((0, 5)), [0] * 5).shape == (0,)
+    base = F.bs5_query_points(300, seed=3)
+    for n in (1, 2, 63, 64, 65, 127, 128, 129, 300):      # ragged against the 128-point workgroup
+        y = c.vectorized_eval_batch(base[:n], [0] * 5)
+        assert y.shape == (n,)
+        assert np.array_equal(y, c.vectorized_eval_batch(base[:300], [0] * 5)[:n])
+    bad = base[:8].copy()
+    bad[1, 2] = np.nan
+    bad[3, 0] = np.inf
+    bad[5, 4] = -np.inf
+    y = c.vectorized_eval_batch(bad, [0] * 5)
+    assert np.isnan(y[[1, 3, 5]]).all() and np.isfinite(y[[0, 2, 4, 6, 7]]).all()
+    with pytest.raises(ValueError):
+        c.vectorized_eval_batch(np.zeros((4, 4)), [0] * 5)
+    with pytest.raises(ValueError):
+        c.vectorized_eval_batch(base[:4], [0] * 4)
+    # non-contiguous / float32 / list inputs are accepted like np.asarray would
+    y1 = c.vectorized_eval_batch(base[::2], [0] * 5)
+    assert np.array_equal(y1, c.vectorized_eval_batch(np.ascontiguousarray(base[::2]), [0] * 5))
+
+
+# ------------------------------------------------------------------ full-size properties
+def test_config2_one_million_points_properties(bs5d, oracle_mod):
+    """BASELINE config 2/4 size (N = 10^6, seed 99): the oracle cannot run all of it in
+    seconds, so: a 20k subset against the oracle, plus size-independent properties."""
+    c, g = bs5d
+    N = 1_000_000
+    pts = F.bs5_query_points(N, seed=99)
+    y = c.vectorized_eval_batch(pts, [0] * 5)
+    assert y.shape == (N,) and np.isfinite(y).all()
+    # subset vs oracle (value and gamma)
+    sub = np.random.default_rng(0).choice(N, 20_000, replace=False)
+    om = _oracle_model(oracle_mod, c)
+    assert_parity(y[sub], oracle_mod.bary_eval_batch(om, pts[sub], [0] * 5), 1e-12, "1M subset value")
+    yg = c.vectorized_eval_batch(pts, [2, 0, 0, 0, 0])
+    assert_parity(yg[sub], oracle_mod.bary_eval_batch(om, pts[sub], [2, 0, 0, 0, 0]), 1e-12,
+                  "1M subset gamma", float("inf"))
+    # permutation equivariance, bit for bit (each point is computed independently)
+    perm = np.random.default_rng(1).permutation(N)
+    assert np.array_equal(c.vectorized_eval_batch(pts[perm], [0] * 5), y[perm])
+    # both kernels agree
+    _set_kernel(c, 1)
+    try:
+        assert_parity(c.vectorized_eval_batch(pts[:50_000], [0] * 5), y[:50_000], 1e-13, "rows vs mfma")
+    finally:
+        _set_kernel(c, 0)
+    # price bounds of a call on [domain]: positive, below spot
+    assert y.min() > 0 and (y < pts[:, 0]).all()
+    # linearity in the tensor and partition of unity
+    T = c.tensor_values
+    rng = np.random.default_rng(2)
+    A = rng.standard_normal(T.shape)
+    ca = ChebyshevApproximation.from_values(A, 5, F.BS5_DOMAIN, F.BS5_NODES)
+    cs = ChebyshevApproximation.from_values(2.0 * T - 3.0 * A, 5, F.BS5_DOMAIN, F.BS5_NODES)
+    ya = ca.vectorized_eval_batch(pts, [0] * 5)
+    ys = cs.vectorized_eval_batch(pts, [0] * 5)
+    assert np.max(np.abs(ys - (2.0 * y - 3.0 * ya))) <= 1e-12 * max(np.max(np.abs(ys)), 1.0)
+    ones = ChebyshevApproximation.from_values(np.ones(T.shape), 5, F.BS5_DOMAIN, F.BS5_NODES)
+    assert np.max(np.abs(ones.vectorized_eval_batch(pts[:200_000], [0] * 5) - 1.0)) < 1e-13
+    assert np.max(np.abs(ones.vectorized_eval_batch(pts[:200_000], [1, 0, 0, 0, 0]))) < 1e-11
+
+
+def test_device_resident_entry_point_matches_host_entry_point(bs5d):
+    c, g = bs5d
+    m = c._model()
+    lib = m.lib
+    N = 100_000
+    pts = F.bs5_query_points(N, seed=5)
+    dp, do = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(lib.pcx_dev_malloc(m.device, pts.nbytes, ctypes.byref(dp)), lib)
+    _lib.check(lib.pcx_dev_malloc(m.device, N * 8, ctypes.byref(do)), lib)
+    try:
+        _lib.check(lib.pcx_memcpy_h2d(m.device, dp, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes), lib)
+        spec = _lib.i32([0, 0, 0, 1, 0])
+        st = ctypes.c_void_p()
+        _lib.check(lib.pcx_bary_stream(m.handle, ctypes.byref(st)), lib)
+        e0, e1 = ctypes.c_void_p(), ctypes.c_void_p()
+        _lib.check(lib.pcx_event_create(m.device, ctypes.byref(e0)), lib)
+        _lib.check(lib.pcx_event_create(m.device, ctypes.byref(e1)), lib)
+        _lib.check(lib.pcx_event_record(e0, st), lib)
+        _lib.check(lib.pcx_bary_eval_batch_dev(m.handle, dp, N, _lib.p_i32(spec), do, None), lib)
+        _lib.check(lib.pcx_event_record(e1, st), lib)
+        ms = ctypes.c_float()
+        _lib.check(lib.pcx_event_elapsed_ms(e0, e1, ctypes.byref(ms)), lib)
+        assert 0.0 < ms.value < 1000.0
+        out = np.empty(N)
+        _lib.check(lib.pcx_memcpy_d2h(m.device, out.ctypes.data_as(ctypes.c_void_p), do, N * 8), lib)
+        assert np.array_equal(out, c.vectorized_eval_batch(pts, [0, 0, 0, 1, 0]))
+        lib.pcx_event_destroy(e0)
+        lib.pcx_event_destroy(e1)
+    finally:
+        lib.pcx_dev_free(m.device, dp)
+        lib.pcx_dev_free(m.device, do)
+
+
+def test_c_abi_argument_errors(bs5d):
+    c, g = bs5d
+    m = c._model()
+    lib = m.lib
+    out = np.empty(4)
+    pts = _lib.f64(F.bs5_query_points(4))
+    bad = _lib.i32([0, 0, 0, 0, 9])
+    assert lib.pcx_bary_eval_batch(m.handle, _lib.p_f64(pts), 4, _lib.p_i32(bad), _lib.p_f64(out)) == _lib.PCX_ERR_INVALID
+    assert b"derivative order" in lib.pcx_last_error()
+    assert lib.pcx_bary_eval_batch(None, _lib.p_f64(pts), 4, None, _lib.p_f64(out)) == _lib.PCX_ERR_INVALID
+    assert lib.pcx_bary_eval_batch(m.handle, _lib.p_f64(pts), -1, None, _lib.p_f64(out)) == _lib.PCX_ERR_INVALID
+    assert lib.pcx_bary_set_kernel(m.handle, 7) == _lib.PCX_ERR_INVALID
+    h = ctypes.c_void_p()
+    n = _lib.i32([3, 0])
+    z = _lib.f64(np.zeros(16))
+    assert lib.pcx_bary_create(0, 2, _lib.p_i32(n), _lib.p_f64(z), _lib.p_f64(z), _lib.p_f64(z), _lib.p_f64(z),
+                               ctypes.byref(h)) == _lib.PCX_ERR_INVALID
+    assert lib.pcx_bary_create(99, 1, _lib.p_i32(n), _lib.p_f64(z), _lib.p_f64(z), _lib.p_f64(z), _lib.p_f64(z),
+                               ctypes.byref(h)) == _lib.PCX_ERR_NO_DEVICE
+    # NULL deriv = value spec
+    _lib.check(lib.pcx_bary_eval_batch(m.handle, _lib.p_f64(pts), 4, None, _lib.p_f64(out)), lib)
+    assert np.array_equal(out, c.vectorized_eval_batch(pts, [0] * 5))

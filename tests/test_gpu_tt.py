@@ -1,0 +1,210 @@
+"""GPU parity tests for the tensor-train path: eval_batch / eval / eval_multi kernels on
+given cores (1e-12 normwise, fp64), and the TT-Cross build against the reference's
+build at equal seed (equal ranks and unique-evaluation counts, eval within 1e-6)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import assert_parity, golden
+import functions as F
+
+from pychebyshev_amd import ChebyshevTT, _lib
+from pychebyshev_amd import tensor_train as tt_mod
+
+pytestmark = pytest.mark.gpu
+
+
+def _cores(g, prefix, d):
+    return [g[f"{prefix}core{k}"] for k in range(d)]
+
+
+def _check_fd(fd, ref, specs, domain, fmax):
+    eps = np.finfo(float).eps
+    for c, spec in enumerate(specs):
+        amp = 1.0
+        for (lo, hi), o_ in zip(domain, spec):
+            amp *= ((hi - lo) * 1e-4) ** int(o_)
+        atol = 400 * eps * fmax / amp if any(spec) else 1e-9 * fmax
+        assert np.max(np.abs(fd[:, c] - ref[:, c])) <= atol, (spec, atol)
+
+
+# ------------------------------------------------------------------ evaluation on given cores
+def test_eval_batch_on_reference_cores():
+    g = golden("g4_tt_bs5d")
+    for mr in (8, 15):
+        tt = ChebyshevTT.from_coeff_cores(_cores(g, f"r{mr}_", 5), F.BS5_DOMAIN)
+        assert tt.tt_ranks == list(g[f"r{mr}_ranks"])
+        assert_parity(tt.eval_batch(g["points"]), g[f"r{mr}_eval"], 1e-12, f"TT r{mr}")
+        one = tt.eval(list(g["points"][7]))
+        assert isinstance(one, float) and abs(one - g[f"r{mr}_eval"][7]) <= 1e-12 * 40
+        fd = np.array([tt.eval_multi(list(s), g["fd_specs"].tolist()) for s in g["scenarios"]])
+        _check_fd(fd, g[f"r{mr}_fd"], g["fd_specs"], F.BS5_DOMAIN, 40.0)
+
+
+def test_eval_batch_rank16_10d_and_dim_order():
+    g = golden("g5_tt_rank16")
+    cores = _cores(g, "", 10)
+    dom = [[-1.0, 1.0]] * 10
+    tt = ChebyshevTT.from_coeff_cores(cores, dom)
+    assert_parity(tt.eval_batch(g["points"]), g["out"], 1e-12, "rank16")
+    perm = [int(v) for v in g["perm"]]
+    ttp = ChebyshevTT.from_coeff_cores(cores, dom, dim_order=perm)
+    assert_parity(ttp.eval_batch(g["points"]), g["out_perm"], 1e-12, "rank16 permuted")
+    for i in range(8):
+        assert abs(ttp.eval(list(g["points"][i])) - g["single"][i]) <= 1e-12 * np.max(np.abs(g["out_perm"]))
+    # eval_multi permutes point and specs once (reference :2304-2315)
+    p = list(g["points"][0])
+    spec = [0] * 10
+    spec[3] = 1
+    v = ttp.eval_multi(p, [[0] * 10, spec])
+    assert abs(v[0] - g["out_perm"][0]) <= 1e-12 * np.max(np.abs(g["out_perm"]))
+    h = 2.0 * 1e-4
+    up, dn = list(p), list(p)
+    up[3] += h
+    dn[3] -= h
+    assert abs(v[1] - (ttp.eval(up) - ttp.eval(dn)) / (2 * h)) < 1e-9
+
+
+def test_eval_batch_mixed_ranks_and_domains():
+    g = golden("g5b_tt_mixed")
+    dom = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
+    tt = ChebyshevTT.from_coeff_cores(_cores(g, "", 4), dom)
+    assert_parity(tt.eval_batch(g["points"]), g["out"], 1e-12, "mixed")
+
+
+@pytest.mark.parametrize("ranks,n", [([1, 20, 24, 1], [5, 6, 4]), ([1, 33, 40, 64, 1], [3, 4, 3, 5]),
+                                     ([1, 1, 1], [9, 2]), ([1, 17, 1], [1, 8])])
+def test_rank_classes_against_oracle(oracle_mod, ranks, n):
+    rng = np.random.default_rng(sum(ranks))
+    d = len(n)
+    cores = [rng.standard_normal((ranks[k], n[k], ranks[k + 1])) / np.sqrt(ranks[k] * n[k]) for k in range(d)]
+    dom = [[-1.0 - k, 2.0 + k] for k in range(d)]
+    pts = np.column_stack([rng.uniform(lo, hi, 1000) for lo, hi in dom])
+    tt = ChebyshevTT.from_coeff_cores(cores, dom)
+    assert_parity(tt.eval_batch(pts), oracle_mod.tt_eval_batch(cores, dom, pts), 1e-12, str(ranks))
+
+
+def test_unsupported_rank_and_edge_batches():
+    rng = np.random.default_rng(0)
+    big = ChebyshevTT.from_coeff_cores([rng.standard_normal((1, 3, 65)), rng.standard_normal((65, 3, 1))], [[0, 1]] * 2)
+    with pytest.raises(NotImplementedError):
+        big.eval_batch(np.zeros((2, 2)))
+    g = golden("g4_tt_bs5d")
+    tt = ChebyshevTT.from_coeff_cores(_cores(g, "r8_", 5), F.BS5_DOMAIN)
+    assert tt.eval_batch(np.zeros((0, 5))).shape == (0,)
+    full = tt.eval_batch(g["points"][:300])
+    for n_ in (1, 63, 64, 65, 255, 256, 257):
+        assert np.array_equal(tt.eval_batch(g["points"][:n_]), full[:n_])
+    assert np.array_equal(tt.eval_batch(g["points"][:300].astype(np.float64).tolist()), full)
+    bad = g["points"][:4].copy()
+    bad[2, 1] = np.nan
+    y = tt.eval_batch(bad)
+    assert np.isnan(y[2]) and np.isfinite(y[[0, 1, 3]]).all()
+    with pytest.raises(ValueError):
+        tt.eval_batch(np.zeros((3, 4)))
+
+
+def test_config3_ten_million_points_properties(oracle_mod):
+    """BASELINE config 3 size (N = 10^7): subset against the oracle + permutation property."""
+    g = golden("g4_tt_bs5d")
+    cores = _cores(g, "r8_", 5)
+    tt = ChebyshevTT.from_coeff_cores(cores, F.BS5_DOMAIN)
+    N = 10_000_000
+    pts = F.bs5_query_points(N, seed=99)
+    y = tt.eval_batch(pts)
+    assert y.shape == (N,) and np.isfinite(y).all()
+    assert np.array_equal(y[:4096], tt.eval_batch(g["points"]))          # same seed-99 prefix
+    sub = np.random.default_rng(0).choice(N, 200_000, replace=False)
+    assert_parity(y[sub], oracle_mod.tt_eval_batch(cores, F.BS5_DOMAIN, pts[sub]), 1e-12, "10M subset")
+    tail = slice(N - 1_000_003, N)
+    perm = np.random.default_rng(1).permutation(1_000_003)
+    assert np.array_equal(tt.eval_batch(pts[tail][perm]), y[tail][perm])
+
+
+# ------------------------------------------------------------------ TT-Cross dense steps
+def test_maxvol_and_dct_match_reference():
+    g = golden("g6_primitives")
+    for t in range(20):
+        assert np.array_equal(tt_mod._maxvol(g[f"mv_A{t}"]), g[f"mv_p{t}"]), t
+    assert np.array_equal(tt_mod._maxvol(np.eye(3)), [0, 1, 2])
+    assert np.max(np.abs(tt_mod._value_core_to_coeff_core(g["vc"]) - g["cc"])) < 1e-14
+    assert np.max(np.abs(tt_mod._value_core_to_coeff_core(g["vc2"]) - g["cc2"])) < 1e-14
+
+
+def test_cross_step_invariants(oracle_mod):
+    rng = np.random.default_rng(5)
+    for (m, c, true_rank, cap) in ((88, 8, 5, 8), (88, 8, 8, 6), (11, 8, 8, 8), (176, 16, 16, 16), (4, 8, 4, 8), (66, 6, 1, 6)):
+        C = rng.standard_normal((m, true_rank)) @ rng.standard_normal((true_rank, c))
+        chat, piv, rank = tt_mod._cross_step(C, cap)
+        want_chat, want_piv, want_rank = oracle_mod._cross_step(C, cap)
+        assert rank == want_rank == min(true_rank, cap, m, c)
+        assert np.array_equal(piv, want_piv[:rank])
+        assert np.max(np.abs(chat[piv] - np.eye(rank))) < 1e-12
+        assert np.max(np.abs(chat - want_chat)) < 1e-10
+    z = tt_mod._cross_step(np.zeros((12, 3)), 3)
+    assert z[2] == 1
+
+
+def test_grid_eval_matches_oracle(oracle_mod):
+    rng = np.random.default_rng(9)
+    ranks, n = [1, 4, 7, 3, 1], [5, 6, 4, 7]
+    cores = [rng.standard_normal((ranks[k], n[k], ranks[k + 1])) for k in range(4)]
+    idx = np.column_stack([rng.integers(0, n[k], 50) for k in range(4)])
+    got = tt_mod._tt_grid_values(cores, idx)
+    want = np.array([oracle_mod.tt_eval_grid(cores, i) for i in idx])
+    assert np.max(np.abs(got - want)) <= 1e-13 * np.max(np.abs(want))
+
+
+# ------------------------------------------------------------------ TT-Cross build
+@pytest.mark.parametrize("mr,sweeps", [(8, 10), (15, 5)])
+def test_tt_cross_build_bs5d_matches_reference(mr, sweeps, capsys):
+    """Config 3 build: ranks and unique-evaluation count equal the reference's at equal
+    seed (docs/benchmarks.md there: max_rank 15 -> [1,11,11,11,7,1], 7,419 evals)."""
+    g = golden("g4_tt_bs5d")
+    tt = ChebyshevTT(F.bs_5d, 5, F.BS5_DOMAIN, F.BS5_NODES, max_rank=mr, max_sweeps=sweeps)
+    tt.build(verbose=True, seed=42)
+    out = capsys.readouterr().out
+    assert f"Building 5D ChebyshevTT (max_rank={mr}, method='cross')..." in out
+    assert "Running TT-Cross..." in out and "TT ranks:" in out and "Compression:" in out
+    assert tt.tt_ranks == list(g[f"r{mr}_ranks"])
+    assert tt.total_build_evals == int(g[f"r{mr}_evals"])
+    assert_parity(tt.eval_batch(g["points"]), g[f"r{mr}_eval"], 1e-6, f"TT-Cross r{mr}")
+    for k in range(5):
+        assert tt._coeff_cores[k].shape == g[f"r{mr}_core{k}"].shape
+    # accuracy vs the closed form at 30 seeded points < 1 % (test_tensor_train.py:83-94 there)
+    pts = F.bs5_query_points(30, seed=11)
+    exact = np.array([F.bs_5d(list(p)) for p in pts])
+    assert np.max(np.abs(tt.eval_batch(pts) - exact) / exact) < 1e-2
+    fd = np.array([tt.eval_multi(list(s), g["fd_specs"].tolist()[:4]) for s in g["scenarios"]])
+    assert np.allclose(fd[:, 0], g[f"r{mr}_fd"][:, 0], rtol=0, atol=1e-5)
+    assert np.allclose(fd[:, 1], g[f"r{mr}_fd"][:, 1], rtol=0, atol=1e-3)
+
+
+def test_tt_cross_build_small_cases_match_reference():
+    g = golden("g7_tt_small")
+    tt = ChebyshevTT(F.sin_sum_3d, 3, [[-1, 1]] * 3, [11, 11, 11], max_rank=5)
+    tt.build(verbose=False, seed=42)
+    assert tt.tt_ranks == list(g["s3_ranks"]) and tt.total_build_evals == int(g["s3_evals"])
+    assert_parity(tt.eval_batch(g["s3_points"]), g["s3_eval"], 1e-6, "3-D sin")
+    tt = ChebyshevTT(F.sin_sum_nd, 10, [[-1, 1]] * 10, [11] * 10, max_rank=16)
+    tt.build(verbose=False, seed=42)
+    assert tt.tt_ranks == list(g["s10_ranks"]) and tt.total_build_evals == int(g["s10_evals"])
+    assert_parity(tt.eval_batch(g["s10_points"]), g["s10_eval"], 1e-6, "10-D sin")
+    tt = ChebyshevTT(F.bs_5d, 5, F.BS5_DOMAIN, [7, 6, 5, 6, 4], max_rank=4, max_sweeps=3)
+    tt.build(verbose=False, seed=7)
+    assert tt.tt_ranks == list(g["x_ranks"]) and tt.total_build_evals == int(g["x_evals"])
+    assert_parity(tt.eval_batch(g["x_points"]), g["x_eval"], 1e-6, "capped BS")
+
+
+def test_additional_data_is_threaded_through_build():
+    seen = []
+
+    def f(x, data):
+        seen.append(data)
+        return data["scale"] * (x[0] + 2 * x[1])
+
+    tt = ChebyshevTT(f, 2, [[0, 1], [0, 1]], [4, 4], max_rank=3, additional_data={"scale": 3.0})
+    tt.build(verbose=False, seed=1)
+    assert seen and all(s == {"scale": 3.0} for s in seen)
+    assert abs(tt.eval([0.25, 0.5]) - 3.0 * 1.25) < 1e-10

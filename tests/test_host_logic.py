@@ -1,0 +1,257 @@
+"""CPU-only checks: host-side mirror of the reference API (constructors, error
+conventions, grid metadata, pickling), the C-ABI library surface, and that the product
+never routes through the oracle.  No GPU compute here."""
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden
+import functions as F
+
+import pychebyshev_amd as pcx
+from pychebyshev_amd import ChebyshevApproximation, ChebyshevTT, Domain, Ns, SpecialPoints, _lib
+from pychebyshev_amd.barycentric import (chebyshev_nodes, compute_barycentric_weights,
+                                         compute_differentiation_matrix)
+from pychebyshev_amd.distributed import shard_bounds
+
+
+# ------------------------------------------------------------------ C ABI surface
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "pcx.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(pcx_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    from pychebyshev_amd import _build
+    _build.build()
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 30
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/pcx.h but not exported"
+    assert sorted(_lib.SIGNATURES) == declared, "ctypes table and header disagree"
+    assert lib.pcx_abi_version() == 1
+
+
+def test_product_fails_loudly_without_device():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is present")
+    c = ChebyshevApproximation.from_values(np.ones((3, 4)), 2, [[0, 1], [0, 1]], [3, 4])
+    with pytest.raises(_lib.PcxLibraryError):
+        c.vectorized_eval_batch(np.zeros((2, 2)), [0, 0])
+    tt = ChebyshevTT.from_coeff_cores([np.ones((1, 3, 1))], [[0, 1]])
+    with pytest.raises(_lib.PcxLibraryError):
+        tt.eval_batch(np.zeros((2, 1)))
+
+
+def test_missing_library_is_an_error(tmp_path):
+    with pytest.raises(_lib.PcxLibraryError):
+        _lib.load(str(tmp_path / "nope.so"))
+
+
+def test_product_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "pychebyshev_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                src = open(os.path.join(base, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f
+                assert "pcx_oracle" not in src and "libpcx_oracle" not in src, f
+
+
+# ------------------------------------------------------------------ grid metadata
+def test_grid_metadata_bit_identical_to_reference():
+    g = golden("g6_primitives")
+    for n in list(range(2, 17)) + [32, 64]:
+        for tag, (a, b) in (("u", (-1.0, 1.0)), ("s", (80.0, 120.0))):
+            x = chebyshev_nodes(a, b, n)
+            assert np.array_equal(x, g[f"x_{tag}{n}"])
+            w = compute_barycentric_weights(x)
+            assert np.array_equal(w, g[f"w_{tag}{n}"])
+            assert np.array_equal(compute_differentiation_matrix(x, w), g[f"D_{tag}{n}"])
+
+
+def test_from_values_matches_reference_state():
+    g = golden("g2_bs5d")
+    c = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES)
+    for k in range(5):
+        assert np.array_equal(c.nodes[k], g[f"nodes{k}"])
+        assert np.array_equal(c.weights[k], g[f"weights{k}"])
+        assert np.array_equal(c.diff_matrices[k], g[f"diff{k}"])
+    assert c.function is None and c.build_time == 0.0 and c.n_evaluations == 0
+    assert repr(c) == "ChebyshevApproximation(dims=5, nodes=[11, 11, 11, 11, 11], built=True)"
+
+
+def test_build_fills_tensor_in_c_order(capsys):
+    calls = []
+
+    def f(x, data):
+        calls.append(tuple(x))
+        return x[0] * 10 + x[1] + data
+
+    c = ChebyshevApproximation(f, 2, [[0, 1], [2, 3]], [3, 2], additional_data=0.5)
+    c.build(verbose=True)
+    out = capsys.readouterr().out
+    assert "Building 2D Chebyshev approximation (6 evaluations)..." in out and "Built in" in out
+    assert "(5 weights, 40 bytes)" in out
+    grid = [(a, b) for a in c.nodes[0] for b in c.nodes[1]]
+    assert calls == grid and c.n_evaluations == 6
+    assert c.tensor_values[2, 1] == c.nodes[0][2] * 10 + c.nodes[1][1] + 0.5
+
+
+def test_from_values_and_nodes_validation():
+    with pytest.raises(ValueError):
+        ChebyshevApproximation.from_values(np.ones((3, 3)), 2, [[0, 1]], [3, 3])
+    with pytest.raises(ValueError):
+        ChebyshevApproximation.from_values(np.ones((3, 4)), 2, [[0, 1], [0, 1]], [3, 3])
+    with pytest.raises(ValueError):
+        ChebyshevApproximation.from_values(np.full((3, 3), np.nan), 2, [[0, 1], [0, 1]], [3, 3])
+    with pytest.raises(ValueError):
+        ChebyshevApproximation.from_values(np.ones((3, 3)), 2, [[1, 1], [0, 1]], [3, 3])
+    with pytest.raises(ValueError):
+        ChebyshevApproximation.nodes(2, [[0, 1]], [3, 3])
+    info = ChebyshevApproximation.nodes(2, [[0, 1], [5, 6]], [3, 2])
+    assert info["shape"] == (3, 2) and info["full_grid"].shape == (6, 2)
+    assert np.array_equal(info["full_grid"][1], [info["nodes_per_dim"][0][0], info["nodes_per_dim"][1][1]])
+
+
+# ------------------------------------------------------------------ error conventions
+def test_constructor_and_unbuilt_errors():
+    f = lambda x, _: 0.0
+    with pytest.raises(ValueError):
+        ChebyshevApproximation(f, 2, [[0, 1], [0, 1]])                       # neither n_nodes nor threshold
+    with pytest.raises(ValueError):
+        ChebyshevApproximation(f, 2, [[0, 1], [0, 1]], [3, None])
+    with pytest.raises(ValueError):
+        ChebyshevApproximation(f, 2, [[0, 1], [0, 1]], [3, 3], max_n=2)
+    with pytest.raises(ValueError):
+        ChebyshevApproximation(f, 2, [[0, 1], [0, 1]], [3, 3], special_points=[[]])
+    with pytest.raises(NotImplementedError):
+        ChebyshevApproximation(f, 1, [[0, 1]], [3], special_points=[[0.5]])
+    c = ChebyshevApproximation(f, 2, Domain([(0, 1), (0, 1)]), Ns([3, 3]), special_points=SpecialPoints([[], []]))
+    assert c.n_nodes == [3, 3] and c.domain == [(0, 1), (0, 1)]
+    for call in (lambda: c.eval([0.5, 0.5], [0, 0]), lambda: c.vectorized_eval([0.5, 0.5], [0, 0]),
+                 lambda: c.vectorized_eval_batch(np.zeros((1, 2)), [0, 0]),
+                 lambda: c.vectorized_eval_multi([0.5, 0.5], [[0, 0]])):
+        with pytest.raises(RuntimeError, match="build"):
+            call()
+    nb = ChebyshevApproximation.from_values(np.ones((3, 3)), 2, [[0, 1], [0, 1]], [3, 3])
+    with pytest.raises(RuntimeError, match="no function"):
+        nb.build()
+
+
+def test_derivative_argument_resolution():
+    c = ChebyshevApproximation.from_values(np.ones((3, 3)), 2, [[0, 1], [0, 1]], [3, 3])
+    with pytest.raises(ValueError):
+        c.vectorized_eval_batch(np.zeros((1, 2)))                            # neither
+    with pytest.raises(ValueError):
+        c.vectorized_eval_batch(np.zeros((1, 2)), [0, 0], derivative_id=0)   # both
+    with pytest.raises(KeyError):
+        c.vectorized_eval_batch(np.zeros((1, 2)), derivative_id=0)           # unknown id
+    assert c.get_derivative_id([1, 0]) == 0 and c.get_derivative_id([0, 2]) == 1
+    assert c.get_derivative_id([1, 0]) == 0
+    assert c._resolve_derivative_args(None, 1) == [0, 2]
+    for bad in ([1], [3, 0], [-1, 0], [1.0, 0]):
+        with pytest.raises(ValueError):
+            c.get_derivative_id(bad)
+    with pytest.raises(ValueError, match="not supported"):
+        # eval() keeps the scalar path's order <= 2 rule; raised before any device work
+        ChebyshevApproximation.from_values(np.ones((4, 4)), 2, [[0, 1], [0, 1]], [4, 4]).eval([0.5, 0.5], [3, 0])
+
+
+def test_pickle_drops_function_and_device_handle(tmp_path):
+    c = ChebyshevApproximation(lambda x, _: x[0], 1, [[0, 1]], [4])
+    c.build(verbose=False)
+    c._device_model = object()     # stand-in: must not be pickled
+    state = c.__getstate__()
+    assert state["function"] is None and "_device_model" not in state
+    assert state["_pychebyshev_version"] == pcx.__version__
+    c._device_model = None
+    c.get_derivative_id([1])
+    path = tmp_path / "m.pkl"
+    c.save(path)
+    back = ChebyshevApproximation.load(path)
+    assert back.function is None and back._device_model is None
+    assert np.array_equal(back.tensor_values, c.tensor_values)
+    assert all(np.array_equal(a, b) for a, b in zip(back.diff_matrices, c.diff_matrices))
+    assert back.get_derivative_id([1]) == 0
+    with pytest.raises(ValueError):
+        c.save(path, format="nope")
+    with pytest.raises(TypeError):
+        with open(tmp_path / "x.pkl", "wb") as fh:
+            pickle.dump({"a": 1}, fh)
+        ChebyshevApproximation.load(tmp_path / "x.pkl")
+    blob = pickle.dumps(c)
+    state = pickle.loads(blob).__dict__
+    assert state["function"] is None
+
+
+def test_tt_constructor_errors_and_properties():
+    f = lambda x, _: 0.0
+    with pytest.raises(ValueError):
+        ChebyshevTT(f, 3, [[0, 1]] * 2, [5, 5, 5])
+    with pytest.raises(ValueError):
+        ChebyshevTT(f, 3, [[0, 1]] * 3, [5, 5])
+    tt = ChebyshevTT(f, 3, Domain([[0, 1]] * 3), Ns([5, 5, 5]), max_rank=4)
+    assert repr(tt) == "ChebyshevTT(dims=3, nodes=[5, 5, 5], max_rank=4, built=False)"
+    assert tt.dim_order == [0, 1, 2] and tt.total_build_evals == 0
+    for call in (lambda: tt.eval([0, 0, 0]), lambda: tt.eval_batch(np.zeros((1, 3))),
+                 lambda: tt.eval_multi([0, 0, 0], [[0, 0, 0]]), lambda: tt.tt_ranks,
+                 lambda: tt.compression_ratio):
+        with pytest.raises(RuntimeError, match="build"):
+            call()
+    with pytest.raises(ValueError, match="'cross', 'svd', or 'als'"):
+        tt.build(verbose=False, method="qr")
+    with pytest.raises(NotImplementedError):
+        tt.build(verbose=False, method="svd")
+    cores = [np.ones((1, 4, 2)), np.ones((2, 3, 1))]
+    w = ChebyshevTT.from_coeff_cores(cores, [[0, 1], [0, 2]], dim_order=[1, 0])
+    assert w.tt_ranks == [1, 2, 1] and w.dim_order == [1, 0] and w.n_nodes == [4, 3]
+    assert w.compression_ratio == 12 / 14
+    state = pickle.loads(pickle.dumps(w))
+    assert state._built and state._device_tt is None and state.function is None
+    with pytest.raises(ValueError):
+        ChebyshevTT.from_coeff_cores([np.ones((1, 4, 2)), np.ones((3, 3, 1))], [[0, 1], [0, 2]])
+    with pytest.raises(ValueError):
+        ChebyshevTT.from_coeff_cores(cores, [[0, 1], [0, 2]], dim_order=[0, 0])
+
+
+def test_tt_fd_rules_replay_on_host():
+    """The two-pass stencil traversal: pass 1 collects points, pass 2 consumes values in
+    the same order -- checked with a stand-in evaluator (no device)."""
+    cores = [np.ones((1, 4, 1)), np.ones((1, 3, 1))]
+    tt = ChebyshevTT.from_coeff_cores(cores, [[0.0, 1.0], [0.0, 2.0]])
+    f = lambda p: p[:, 0] ** 2 * 3 + p[:, 0] * p[:, 1] + np.sin(p[:, 1])
+    seen = []
+
+    def fake(pts):
+        seen.append(np.array(pts))
+        return f(np.asarray(pts))
+    tt._eval_user_points = fake
+    out = tt.eval_multi([0.3, 1.1], [[0, 0], [1, 0], [2, 0], [1, 1], [0, 2], [2, 1]])
+    assert len(seen) == 1 and seen[0].shape == (1 + 2 + 3 + 4 + 3 + 6, 2)
+    x, y = 0.3, 1.1
+    exact = [f(np.array([[x, y]]))[0], 6 * x + y, 6.0, 1.0, -np.sin(y), 0.0]
+    assert np.allclose(out[:5], exact[:5], atol=2e-7) and abs(out[5]) < 1e-3  # nested 3rd order: eps/h^3 noise
+    # boundary nudge: at the domain corner the stencil stays inside [a + 0.5h, b - 0.5h]
+    seen.clear()
+    tt.eval_multi([0.0, 2.0], [[1, 0], [0, 2]])
+    pts = seen[0]
+    assert pts[:, 0].min() >= 0.0 and pts[:, 1].max() <= 2.0
+    with pytest.raises(ValueError, match="not supported"):
+        tt.eval_multi([0.3, 1.1], [[3, 0]])
+
+
+def test_shard_bounds_cover_everything_once():
+    for n in (0, 1, 7, 8, 1_000_003):
+        for g in (1, 2, 3, 8):
+            blocks = [shard_bounds(n, r, g) for r in range(g)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(blocks, blocks[1:]))
+            assert all(lo <= hi for lo, hi in blocks)
+    with pytest.raises(ValueError):
+        shard_bounds(10, 2, 2)
