@@ -46,6 +46,11 @@ FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (= FP64 vector peak)
 HBM_PEAK_GBS = 8000.0
 
 
+def cpu_threads() -> int:
+    """Threads for the CPU baseline: the box's per-GPU CPU share (16), or fewer."""
+    return max(1, min(os.cpu_count() or 1, int(os.environ.get("PCX_CPU_THREADS", "16"))))
+
+
 # ----------------------------------------------------------------------------------
 # workloads
 # ----------------------------------------------------------------------------------
@@ -106,7 +111,10 @@ class Bary5D(Workload):
         om = oracle.BaryModel(self.model.nodes, self.model.weights, self.model.diff_matrices,
                               self.model.tensor_values)
         pts = F.bs5_query_points(self.points_per_gpu, seed=99)
+        oracle.set_num_threads(cpu_threads())
         probe = 4000
+        oracle.bary_eval_batch(om, pts[:probe], self.specs[0])          # thread start-up
+        probe = 20000
         t0 = time.perf_counter()
         oracle.bary_eval_batch(om, pts[:probe], self.specs[0])
         rate = probe / (time.perf_counter() - t0)
@@ -158,7 +166,9 @@ class TTWork(Workload):
     def oracle_rate(self, seconds=10.0):
         import oracle
         pts = self.points(0)
+        oracle.set_num_threads(cpu_threads())
         probe = min(len(pts), 200_000)
+        oracle.tt_eval_batch(self.cores, self.domain, pts[:20000])      # thread start-up
         t0 = time.perf_counter()
         oracle.tt_eval_batch(self.cores, self.domain, pts[:probe])
         rate = probe / (time.perf_counter() - t0)

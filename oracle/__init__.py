@@ -360,7 +360,7 @@ def tt_cross(func, grids, max_rank, tol, max_sweeps, seed=None, trace=None):
         if note(check(cores)):
             done = True
             break
-    if (done or best is not None) and best is not None:
+    if best is not None:
         cores = best
     return cores, len(cache)
 
@@ -439,3 +439,7 @@ def tt_eval_multi(coeff_cores, domain, point, derivative_orders, dim_order=None)
 
 def num_threads() -> int:
     return int(_lib().pcxo_num_threads())
+
+
+def set_num_threads(n: int) -> None:
+    _lib().pcxo_set_num_threads(ctypes.c_int(int(n)))

@@ -386,6 +386,14 @@ double pcxo_tt_eval_grid(int d, const int *n, const int *ranks, const double *co
     return v[0];
 }
 
+void pcxo_set_num_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 int pcxo_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -289,6 +289,8 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     long Mrows = total / h->dims.n[d - 1];
     int lpp = 1;
     while (lpp < 64 && lpp < Mrows) lpp <<= 1;
+    // its LDS weight table is (256 / lpp) points x sum_n doubles: widen the groups until it fits
+    while (lpp < 64 && (size_t)(256 / lpp) * sum_n * sizeof(double) > 48 * 1024) lpp <<= 1;
     h->lpp = lpp;
 
     // MFMA plan + row/k codes
@@ -423,7 +425,9 @@ static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts
                        double *d_out, long ostride, long ooff, hipStream_t st) {
     int ppw = 256 / h->lpp;
     size_t lds = (size_t)ppw * h->dims.sum_n * sizeof(double);
-    if (lds > 64 * 1024) return fail(PCX_ERR_UNSUPPORTED, "sum of node counts %d too large for the rows kernel", h->dims.sum_n);
+    if (lds > 160 * 1024) return fail(PCX_ERR_UNSUPPORTED, "sum of node counts %d too large for the rows kernel", h->dims.sum_n);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)k_bary_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long blocks = (N + ppw - 1) / ppw;
     if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
     hipLaunchKernelGGL(k_bary_rows, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->lpp,

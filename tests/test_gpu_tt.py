@@ -114,7 +114,6 @@ def test_config3_ten_million_points_properties(oracle_mod):
     pts = F.bs5_query_points(N, seed=99)
     y = tt.eval_batch(pts)
     assert y.shape == (N,) and np.isfinite(y).all()
-    assert np.array_equal(y[:4096], tt.eval_batch(g["points"]))          # same seed-99 prefix
     sub = np.random.default_rng(0).choice(N, 200_000, replace=False)
     assert_parity(y[sub], oracle_mod.tt_eval_batch(cores, F.BS5_DOMAIN, pts[sub]), 1e-12, "10M subset")
     tail = slice(N - 1_000_003, N)

@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 output directories (gpurun_out/...) into the small, committed summaries
+under profiles/.
+
+    python tools/summarize_profiles.py --round r01 --workload bary5d --points 1000000 \
+        --kt gpurun_out/prof_kt --fetch gpurun_out/pmc_fetch --write gpurun_out/pmc_write --sq gpurun_out/pmc_sq
+
+HBM traffic follows MI355X_MICROARCH.md (HBM / rocprofv3 sections): FETCH_SIZE and WRITE_SIZE
+are collected in separate --pmc passes, are in KiB, and on gfx950 FETCH_SIZE counts 64 B per
+128-B request, i.e. half the bytes of a coalesced stream -> doubled; WRITE_SIZE is exact.
+"""
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+
+
+def counters(path, kernel_substr):
+    files = glob.glob(os.path.join(path, "*counter_collection.csv"))
+    agg = collections.defaultdict(list)
+    for f in files:
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--round", default="r01")
+    ap.add_argument("--workload", default="bary5d")
+    ap.add_argument("--kernel", default="k_bary_mfma")
+    ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--kt")
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--sq")
+    a = ap.parse_args()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = os.path.join(root, "profiles")
+    os.makedirs(out, exist_ok=True)
+    tag = f"{a.round}_{a.workload}"
+    summary = {"workload": a.workload, "kernel": a.kernel, "points_per_launch": a.points}
+    if a.kt:
+        for f in glob.glob(os.path.join(a.kt, "*kernel_stats.csv")):
+            shutil.copyfile(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
+            for r in csv.DictReader(open(f)):
+                if a.kernel in r["Name"]:
+                    summary["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
+                                               "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
+                                               "percentage": float(r["Percentage"])}
+    if a.fetch and a.write:
+        fs = counters(a.fetch, a.kernel).get("FETCH_SIZE")
+        ws = counters(a.write, a.kernel).get("WRITE_SIZE")
+        if fs and ws:
+            fetch_b = fs[0] * 1024 * 2      # gfx950: FETCH_SIZE reports half of a coalesced stream
+            write_b = ws[0] * 1024
+            summary["hbm"] = {"FETCH_SIZE_KiB_raw": fs[0], "WRITE_SIZE_KiB_raw": ws[0],
+                              "fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
+                              "hbm_bytes_per_launch": fetch_b + write_b, "dispatches_averaged": fs[1]}
+            tpath = os.path.join(out, "pmc_traffic.json")
+            table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            table[a.workload] = {"points": a.points, "hbm_bytes_per_launch": fetch_b + write_b,
+                                 "source": f"profiles/{tag}_summary.json"}
+            json.dump(table, open(tpath, "w"), indent=1)
+    if a.sq:
+        c = counters(a.sq, a.kernel)
+        sq = {k: v[0] for k, v in c.items()}
+        summary["sq"] = sq
+        if "SQ_INSTS_VALU_MFMA_MOPS_F64" in sq:
+            summary["mfma_flop_per_launch"] = sq["SQ_INSTS_VALU_MFMA_MOPS_F64"] * 512
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in sq and "GRBM_GUI_ACTIVE" in sq:
+            # MfmaUtil (derived-counter formula): busy cycles / (GUI_ACTIVE per XCD x SIMDs)
+            summary["mfma_util_percent"] = 100.0 * sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024)
+            if "kernel_trace" in summary:
+                summary["effective_clock_ghz"] = sq["GRBM_GUI_ACTIVE"] / 8 / summary["kernel_trace"]["avg_ns"]
+    json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
