@@ -207,12 +207,25 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    # The contract is ONE JSON line on stdout.  RCCL/torch print banners to the C-level
+    # stdout at init, so keep the real stdout aside and point fd 1 at stderr meanwhile.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     dist = torch = None
-    if world > 1:
+    # PCX_BENCH_FORCE_TORCH=1 exercises the multi-GPU plumbing (nccl group, shared stream,
+    # gather) with a single rank, so that path can be rehearsed on a one-GPU box.
+    if world > 1 or os.environ.get("PCX_BENCH_FORCE_TORCH") == "1":
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     os.environ["PCX_DEVICE"] = str(local_rank)
     lib = _lib.load()
@@ -334,7 +347,7 @@ def main():
             "config": {"workload": wl.name, "points_per_gpu_per_step": n,
                        "evals_per_point": wl.evals_per_point,
                        "parallelism": f"batch-sharded x{world}, model replicated"
-                                      + (", RCCL gather of results each step" if world > 1 else "")},
+                                      + (", RCCL gather of results each step" if dist is not None else "")},
             "roofline": {"bound": "mfma", "kernel": wl.kernel, "achieved": achieved,
                          "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
@@ -349,7 +362,8 @@ def main():
             line["cpu_baseline"] = {"value": rate, "unit": "point-evals/s", "cores": cores,
                                     "kind": "port", "sample": sample,
                                     "host_cpus": os.cpu_count()}
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
     if dist is not None:
         dist.barrier()

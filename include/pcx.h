@@ -114,6 +114,9 @@ int pcx_tt_destroy(pcx_tt *h);
 int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double *out);
 int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, double *d_out, void *stream);
 int pcx_tt_stream(pcx_tt *h, void **stream);
+/* Kernel selection: 0 = auto, 1 = direct form (one MFMA GEMM over (node, left rank) per
+ * dimension; ranks <= 64), 2 = small-rank "W first" form (ranks <= 12, cores in LDS).   */
+int pcx_tt_set_kernel(pcx_tt *h, int variant);
 
 /* ---- TT-Cross build steps (tensor_train.py:123-540) ------------------------- */
 /* One unfolding step of _tt_cross (:332-362 and :449-474): thin SVD of the m x c cross

@@ -73,6 +73,7 @@ SIGNATURES = {
     "pcx_tt_eval_batch": (_I, [_V, c_f64p, _L, c_f64p]),
     "pcx_tt_eval_batch_dev": (_I, [_V, _V, _L, _V, _V]),
     "pcx_tt_stream": (_I, [_V, c_vpp]),
+    "pcx_tt_set_kernel": (_I, [_V, _I]),
     "pcx_tt_cross_step": (_I, [_I, c_f64p, _I, _I, _I, _D, c_f64p, c_i64p, c_i32p]),
     "pcx_maxvol": (_I, [_I, c_f64p, _I, _I, _D, _I, c_i64p]),
     "pcx_tt_value_to_coeff_core": (_I, [_I, c_f64p, _I, _I, _I, c_f64p]),

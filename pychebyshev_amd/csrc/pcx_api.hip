@@ -554,6 +554,13 @@ struct pcx_tt {
     int rmax = 1;
     int cls = 0;  // 0: RC<=4,RT=1,NT=4   1: RC<=8,RT=2,NT=2   2: RC<=16,RT=4,NT=1
     double *d_frag = nullptr;
+    double *d_last = nullptr;   // plain last core [a][j] (right rank 1) for the VALU tail
+    int rl_last = 1;
+    // small-rank "W first" form (ranks <= 12, packed cores resident in LDS)
+    int wR = 0;           // 0 = not available, else padded rank 4 / 8 / 12
+    TTWPlan wplan;
+    double *d_img = nullptr;
+    int variant = 0;      // 0 auto, 1 direct form, 2 W-first form
     std::mutex mu;
     Scratch s_pts, s_out;
 };
@@ -563,6 +570,8 @@ extern "C" int pcx_tt_destroy(pcx_tt *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     (void)hipFree(h->d_frag);
+    (void)hipFree(h->d_last);
+    (void)hipFree(h->d_img);
     h->s_pts.release(); h->s_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -596,16 +605,24 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
         h->dims.col[k] = col;
         h->dims.lo[k] = lo[k];
         h->dims.hi[k] = hi[k];
-        h->rk.rc[k] = (ranks[k] + 3) / 4;
-        h->rk.rt[k] = (ranks[k + 1] + 15) / 16;
-        h->dims.frag_off[k] = frag_total;
-        frag_total += (long)n_nodes[k] * h->rk.rc[k] * h->rk.rt[k] * 64;
         coff[k] = core_total;
         core_total += (long)ranks[k] * n_nodes[k] * ranks[k + 1];
         h->rmax = std::max(h->rmax, std::max(ranks[k], ranks[k + 1]));
     }
     if (h->rmax > 64) { delete h; return fail(PCX_ERR_UNSUPPORTED, "TT rank %d > 64 not covered by the MFMA kernel", h->rmax); }
     h->cls = h->rmax <= 16 ? 0 : (h->rmax <= 32 ? 1 : 2);
+    // direct form: dim 0 stores one left chunk; later dims are padded to the kernel's
+    // compile-time RC chunks x RT tiles so that its node loop is branch-free
+    {
+        const int RCk = h->cls == 0 ? (h->rmax + 3) / 4 : (h->cls == 1 ? 8 : 16);
+        const int RTk = h->cls == 0 ? 1 : (h->cls == 1 ? 2 : 4);
+        for (int k = 0; k < d; ++k) {
+            h->rk.rc[k] = (k == 0) ? 1 : RCk;
+            h->rk.rt[k] = RTk;
+            h->dims.frag_off[k] = frag_total;
+            frag_total += (long)n_nodes[k] * h->rk.rc[k] * h->rk.rt[k] * 64;
+        }
+    }
 
 #define CREATE_TRY(expr)                                                                   \
     do {                                                                                   \
@@ -621,11 +638,44 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
     double *d_cores = nullptr;
     CREATE_TRY(hipMalloc((void **)&d_cores, core_total * sizeof(double)));
     CREATE_TRY(hipMemcpy(d_cores, cores_cat, core_total * sizeof(double), hipMemcpyHostToDevice));
+    h->rl_last = ranks[d - 1];
+    CREATE_TRY(hipMalloc((void **)&h->d_last, (size_t)ranks[d - 1] * n_nodes[d - 1] * sizeof(double)));
+    CREATE_TRY(hipMemcpy(h->d_last, cores_cat + coff[d - 1], (size_t)ranks[d - 1] * n_nodes[d - 1] * sizeof(double), hipMemcpyHostToDevice));
     for (int k = 0; k < d; ++k) {
         long cnt = (long)n_nodes[k] * h->rk.rc[k] * h->rk.rt[k] * 64;
         hipLaunchKernelGGL(k_tt_pack_core, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream,
                            d_cores + coff[k], h->d_frag + h->dims.frag_off[k], ranks[k], n_nodes[k],
                            ranks[k + 1], h->rk.rc[k], h->rk.rt[k]);
+    }
+    // W-first image (small ranks): every dim but the last as (R*R) x n GEMM fragments, the
+    // last dim as a plain [a][j] table; the whole image must fit the kernel's LDS budget.
+    if (h->rmax <= 12) {
+        int R = 4 * ((h->rmax + 3) / 4);
+        long total = 0;
+        for (int k = 0; k < d; ++k) {
+            h->wplan.ks[k] = (n_nodes[k] + 3) / 4;
+            h->wplan.ntiles[k] = (k == 0) ? (R + 15) / 16 : R * R / 16;   // compile-time tile counts of the kernel
+            h->wplan.lds_off[k] = (int)total;
+            total += (k == d - 1) ? (long)ranks[k] * n_nodes[k]
+                                  : (long)h->wplan.ks[k] * h->wplan.ntiles[k] * 64;
+        }
+        for (int k = d; k < PCX_MAX_DIMS; ++k) { h->wplan.ks[k] = 0; h->wplan.ntiles[k] = 0; h->wplan.lds_off[k] = 0; }
+        h->wplan.rl_last = ranks[d - 1];
+        h->wplan.total = (int)total;
+        if (total * (long)sizeof(double) <= 96 * 1024) {
+            h->wR = R;
+            if (hipMalloc((void **)&h->d_img, total * sizeof(double)) != hipSuccess) h->wR = 0;
+        }
+        for (int k = 0; k < d && h->wR; ++k) {
+            int last = (k == d - 1);
+            long cnt = last ? (long)ranks[k] * n_nodes[k] : (long)h->wplan.ks[k] * h->wplan.ntiles[k] * 64;
+            dim3 grid((unsigned)((cnt + 255) / 256)), block(256);
+            double *dst = h->d_img + h->wplan.lds_off[k];
+            const double *src = d_cores + coff[k];
+            if (R == 4) hipLaunchKernelGGL(k_tt_pack_wfirst<4>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], h->wplan.ks[k], h->wplan.ntiles[k], last);
+            else if (R == 8) hipLaunchKernelGGL(k_tt_pack_wfirst<8>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], h->wplan.ks[k], h->wplan.ntiles[k], last);
+            else hipLaunchKernelGGL(k_tt_pack_wfirst<12>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], h->wplan.ks[k], h->wplan.ntiles[k], last);
+        }
     }
     hipError_t e1 = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(h->stream);
@@ -637,13 +687,36 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
     return PCX_OK;
 }
 
+template <int R, int NT>
+static int tt_launch_wfirst(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
+    auto kern = k_tt_eval_wfirst<R, NT>;
+    size_t lds = ((size_t)h->wplan.total + (size_t)4 * 16 * NT * h->dims.d) * sizeof(double);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long per_wg = 4L * 16 * NT;
+    long batches = (N + per_wg - 1) / per_wg;
+    // persistent workgroups: enough to fill every CU a few times over, each walks a
+    // grid-stride range of batches so the LDS image is loaded once per workgroup
+    long blocks = std::min<long>(batches, 256L * 8);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->wplan, h->d_img, d_pts, d_out, N);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
 static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
     if (N == 0) return PCX_OK;
+    if (h->variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
+    if (h->wR && h->variant != 1) {
+        if (h->wR == 4) return tt_launch_wfirst<4, 4>(h, d_pts, N, d_out, st);
+        if (h->wR == 8) return tt_launch_wfirst<8, 2>(h, d_pts, N, d_out, st);
+        return tt_launch_wfirst<12, 1>(h, d_pts, N, d_out, st);
+    }
     auto go = [&](auto kern, int nt) -> int {
         long per_wg = 4L * 16 * nt;
         long blocks = (N + per_wg - 1) / per_wg;
         if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, st, h->dims, h->rk, h->d_frag, d_pts, d_out, N);
+        size_t lds = (size_t)4 * 16 * nt * h->dims.d * sizeof(double);   // the workgroup's query rows
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->rk, h->d_frag, h->d_last, h->rl_last, d_pts, d_out, N);
         HIP_TRY(hipGetLastError());
         return PCX_OK;
     };
@@ -686,6 +759,14 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
         HIP_TRY(hipMemcpyAsync(out + start, dout, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
+    return PCX_OK;
+}
+
+extern "C" int pcx_tt_set_kernel(pcx_tt *h, int variant) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (variant < 0 || variant > 2) return fail(PCX_ERR_INVALID, "variant %d outside [0, 2]", variant);
+    if (variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
+    h->variant = variant;
     return PCX_OK;
 }
 

@@ -14,6 +14,8 @@
 // movement and no LDS.
 #pragma once
 
+#include <type_traits>
+
 #include "pcx_common.h"
 
 // Core packing: frag[dim][j][c][t][l] = G[a = 4c + (l>>4)][j][b = 16t + (l&15)], zero padded;
@@ -34,16 +36,86 @@ __global__ void k_tt_pack_core(const double *__restrict__ G, double *__restrict_
     frag[idx] = (a < rl && b < rr) ? G[((long)a * n + j) * rr + b] : 0.0;
 }
 
+// ---- one dimension of the direct form -------------------------------------------------
+// acc[nt][t] += sum_j sum_{c < RCX} mfma(frag[j][c][t], v[nt][c] * T_j(s[nt])).
+// RCX/RT are compile-time: every loop below is fully unrolled and branch-free, the
+// fragments of node j+1 are in flight (registers, ping-pong) while node j is multiplied.
+template <int RCX, int RT, int NT>
+__device__ __forceinline__ void tt_mfma_nodes(const double *__restrict__ fk, int n,
+                                              const double (&v)[NT][RCX > 0 ? RCX : 1],
+                                              const double (&s)[NT], pcx_d4 (&acc)[NT][RT]) {
+    constexpr int F = RCX * RT;          // fragments per node
+    constexpr bool PINGPONG = (F <= 8);
+    double tprev[NT], tcur[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { tprev[nt] = 1.0; tcur[nt] = s[nt]; }
+
+    auto load = [&](double (&a)[F], int j) {
+        const double *fj = fk + (size_t)j * F * 64;
+#pragma unroll
+        for (int f = 0; f < F; ++f) a[f] = fj[f * 64];
+    };
+    auto node = [&](const double (&a)[F], int j) {
+        double q[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if (j == 0) q[nt] = 1.0;
+            else if (j == 1) q[nt] = s[nt];
+            else {
+                double tn = __builtin_fma(2.0 * s[nt], tcur[nt], -tprev[nt]);
+                tprev[nt] = tcur[nt];
+                tcur[nt] = tn;
+                q[nt] = tn;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < RCX; ++c) {
+            double bop[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bop[nt] = v[nt][c] * q[nt];
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c * RT + t], bop[nt], acc[nt][t], 0, 0, 0);
+        }
+    };
+
+    if (PINGPONG) {
+        double a0[F], a1[F];
+        load(a0, 0);
+        for (int j = 0; j < n; j += 2) {
+            load(a1, (j + 1 < n) ? j + 1 : j);
+            node(a0, j);
+            if (j + 1 < n) {
+                load(a0, (j + 2 < n) ? j + 2 : j + 1);
+                node(a1, j + 1);
+            }
+        }
+    } else {
+        for (int j = 0; j < n; ++j) {
+            double a[F];
+            load(a, j);
+            node(a, j);
+        }
+    }
+}
+
+// Packing for the direct form: dim 0 keeps its single left chunk, every later dim is
+// padded to the kernel's compile-time RC chunks and RT tiles (zeros), so the node loop
+// needs no rank predicates:  frag[dim][j][c][t][l] = G[a = 4c + (l>>4)][j][b = 16t + (l&15)].
 struct TTRanks {
-    int rc[PCX_MAX_DIMS];  // left-rank chunks of 4 per storage dim
-    int rt[PCX_MAX_DIMS];  // right-rank tiles of 16 per storage dim
+    int rc[PCX_MAX_DIMS];  // left-rank chunks of 4 stored per storage dim (1 for dim 0, RC after)
+    int rt[PCX_MAX_DIMS];  // right-rank tiles of 16 stored per storage dim (RT)
 };
 
-// One wave owns 16*NT points.  RC/RT are compile-time upper bounds for the register
-// arrays; the per-dimension chunk/tile counts are wave-uniform runtime values.
+// One wave owns 16*NT points; v (lane group g holds rows a = 4c + g) runs through the
+// dimensions in registers.  The last dimension (right rank 1) is a VALU dot product against
+// the plain core `glast` ([a][j]) split over the four lane groups.
 template <int RC, int RT, int NT>
 __global__ void __launch_bounds__(256)
 k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
+               const double *__restrict__ glast, int rl_last,
                const double *__restrict__ pts, double *__restrict__ out, long N) {
     static_assert(RC <= 4 * RT, "left chunks must fit the previous D tiles");
     const int lane = threadIdx.x & 63;
@@ -51,79 +123,99 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
     const int g = lane >> 4;
     const int c16 = lane & 15;
     const long base = ((long)blockIdx.x * 4 + wave) * (16 * NT);
+    const int d = dims.d;
+
+    // The wave's 16*NT query rows are one contiguous block of `pts`: copy it to LDS with
+    // coalesced loads once, instead of a strided global load per dimension.
+    extern __shared__ double lds_x[];
+    double *xs = lds_x + (size_t)wave * (16 * NT) * d;
+    {
+        const long first = base * d;
+        const long avail = (N - base) * (long)d;              // doubles that exist
+        const int cnt = 16 * NT * d;
+        for (int i = lane; i < cnt; i += 64) xs[i] = (i < avail) ? pts[first + i] : 0.0;
+    }
+    __syncthreads();
 
     double v[NT][RC];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int c = 0; c < RC; ++c) v[nt][c] = 0.0;
-        v[nt][0] = (g == 0) ? 1.0 : 0.0;   // v = e_0 (rank-1 left boundary)
-    }
 
-    for (int k = 0; k < dims.d; ++k) {
-        const int n = dims.n[k];
-        const int rc = rk.rc[k];
-        const int rt = rk.rt[k];
-        const double lo = dims.lo[k], hi = dims.hi[k];
-        double s[NT], tprev[NT], tcur[NT];
+    if (d > 1) {
+        // dimension 0: left rank 1 -> a single chunk whose only non-zero row is a = 0
+        double v0[NT][1], s[NT];
+        pcx_d4 acc[NT][RT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            long p = base + 16 * nt + c16;
-            double x = (p < N) ? pts[p * dims.d + dims.col[k]] : lo;
-            s[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;   // tensor_train.py:2254
-            tprev[nt] = 1.0;
-            tcur[nt] = s[nt];
+            v0[nt][0] = (g == 0) ? 1.0 : 0.0;
+            double x = xs[(16 * nt + c16) * d + dims.col[0]];
+            s[nt] = 2.0 * (x - dims.lo[0]) / (dims.hi[0] - dims.lo[0]) - 1.0;   // tensor_train.py:2254
+#pragma unroll
+            for (int t = 0; t < RT; ++t) acc[nt][t] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
         }
-        pcx_d4 acc[NT][RT];
+        tt_mfma_nodes<1, RT, NT>(frag + dims.frag_off[0] + lane, dims.n[0], v0, s, acc);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int t = 0; t < RT; ++t) acc[nt][t] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < RC; ++c) v[nt][c] = acc[nt][c >> 2][c & 3];
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) v[nt][0] = (g == 0) ? 1.0 : 0.0;
+    }
 
-        const double *fk = frag + dims.frag_off[k] + lane;
-        for (int j = 0; j < n; ++j) {
-            double q[NT];
+    for (int k = 1; k < d - 1; ++k) {
+        const double lo = dims.lo[k], hi = dims.hi[k];
+        double s[NT];
+        pcx_d4 acc[NT][RT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                if (j == 0) q[nt] = 1.0;
-                else if (j == 1) q[nt] = s[nt];
-                else {
-                    double tn = __builtin_fma(2.0 * s[nt], tcur[nt], -tprev[nt]);
-                    tprev[nt] = tcur[nt];
-                    tcur[nt] = tn;
-                    q[nt] = tn;
-                }
-            }
-            const double *fj = fk + (size_t)j * rc * rt * 64;
+        for (int nt = 0; nt < NT; ++nt) {
+            double x = xs[(16 * nt + c16) * d + dims.col[k]];
+            s[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;
 #pragma unroll
-            for (int c = 0; c < RC; ++c) {
-                if (c < rc) {
-                    double bop[NT];
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bop[nt] = v[nt][c] * q[nt];
-#pragma unroll
-                    for (int t = 0; t < RT; ++t) {
-                        if (t < rt) {
-                            double a = fj[(size_t)(c * rt + t) * 64];
-#pragma unroll
-                            for (int nt = 0; nt < NT; ++nt)
-                                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(
-                                    a, bop[nt], acc[nt][t], 0, 0, 0);
-                        }
-                    }
-                }
-            }
+            for (int t = 0; t < RT; ++t) acc[nt][t] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
         }
+        tt_mfma_nodes<RC, RT, NT>(frag + dims.frag_off[k] + lane, dims.n[k], v, s, acc);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int c = 0; c < RC; ++c) v[nt][c] = acc[nt][c >> 2][c & 3];
     }
 
+    // last dimension: y = sum_a v[a] * sum_j T_j(s) G[a][j]; lane group g owns a = 4c + g
+    {
+        const int k = d - 1;
+        const int n = dims.n[k];
+        const double lo = dims.lo[k], hi = dims.hi[k];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        long p = base + 16 * nt + c16;
-        if (g == 0 && p < N) out[p] = v[nt][0];
+        for (int nt = 0; nt < NT; ++nt) {
+            long p = base + 16 * nt + c16;
+            double x = xs[(16 * nt + c16) * d + dims.col[k]];
+            double sc = 2.0 * (x - lo) / (hi - lo) - 1.0;
+            double w[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) w[c] = 0.0;
+            double tp = 1.0, tc = sc;
+            for (int j = 0; j < n; ++j) {
+                double q;
+                if (j == 0) q = 1.0;
+                else if (j == 1) q = sc;
+                else { q = __builtin_fma(2.0 * sc, tc, -tp); tp = tc; tc = q; }
+#pragma unroll
+                for (int c = 0; c < RC; ++c) {
+                    int a = 4 * c + g;
+                    double gv = (a < rl_last) ? glast[a * n + j] : 0.0;
+                    w[c] = __builtin_fma(q, gv, w[c]);
+                }
+            }
+            double y = 0.0;
+#pragma unroll
+            for (int c = 0; c < RC; ++c) y = __builtin_fma(v[nt][c], w[c], y);
+            y += __shfl_xor(y, 16, 64);
+            y += __shfl_xor(y, 32, 64);
+            if (g == 0 && p < N) out[p] = y;
+        }
     }
 }
 
@@ -150,4 +242,218 @@ __global__ void k_tt_grid_eval(int d, const int *__restrict__ n, const int *__re
         double *sw = v; v = v2; v2 = sw;
     }
     out[p] = v[0];
+}
+
+// =====================================================================================
+// Small-rank form ("W first"): for ranks <= 12 the direct form above wastes half of every
+// MFMA (r' rows padded to 16).  Here each dimension is ONE dense GEMM over the node index
+//     W[(a,b), p] = sum_j G_k[a, j, b] * T_j(s_k(p))          rows = R*R, K = n_k -> KS*4
+// (A = core viewed as an (R*R) x n matrix, B = the Chebyshev polynomial values alone),
+// followed by the per-point contraction v'[b] = sum_a v[a] W[(a,b)] on the VALU:
+//   D layout: lane (p = l&15, g = l>>4), tile t, reg i holds row m = 16t + g + 4i = 4u + g
+//   with u = 4t + i, and with rows ordered m = a*R + b (R a multiple of 4):
+//   a = u / (R/4), b = 4 (u % (R/4)) + g   ->  lane g owns outputs b = g, g+4, ..., the
+//   products need only compile-time register indices, and one shuffle per b re-assembles
+//   v' in every lane.  All packed cores live in LDS for the whole kernel.
+// The last dimension (r' = 1) is a VALU dot product split over the four lane groups.
+// =====================================================================================
+struct TTWPlan {
+    int ks[PCX_MAX_DIMS];       // k-steps of 4 covering n_k
+    int ntiles[PCX_MAX_DIMS];   // row tiles stored: ceil(R/16) for dim 0 (left rank 1), R*R/16 after
+    int lds_off[PCX_MAX_DIMS];  // offset (doubles) of dim k's block inside the LDS image
+    int rl_last;                // left rank of the last dimension
+    int total;                  // doubles in the LDS image
+};
+
+// image layout: for k < d-1: frag[k][s][t][64] = G_k[a][4s + (l>>4)][b], m = 16t + (l&15),
+// a = m / R, b = m % R (zero outside the core); last dim: plain [a][j] (rank 1 on the right).
+template <int R>
+__global__ void k_tt_pack_wfirst(const double *__restrict__ G, double *__restrict__ img, int rl,
+                                 int n, int rr, int ks, int ntiles, int is_last) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (is_last) {
+        if (idx < (long)rl * n) img[idx] = G[idx];   // (rl, n, 1) is already [a][j]
+        return;
+    }
+    long total = (long)ks * ntiles * 64;
+    if (idx >= total) return;
+    int l = (int)(idx & 63);
+    int t = (int)((idx >> 6) % ntiles);
+    int s = (int)((idx >> 6) / ntiles);
+    int m = 16 * t + (l & 15);
+    int a = m / R, b = m % R;
+    int j = 4 * s + (l >> 4);
+    img[idx] = (a < rl && b < rr && j < n) ? G[((long)a * n + j) * rr + b] : 0.0;
+}
+
+// One dimension of the W-first form with TL (compile-time) row tiles:
+//   acc[nt][t] = sum_s mfma(frag[s][t], B = T_{4s + g}(x))       (branch-free, unrolled)
+template <int TL, int NT>
+__device__ __forceinline__ void tt_w_gemm(const double *fk, int n, int ks, int g,
+                                          const double (&sc)[NT], pcx_d4 (&acc)[NT][TL]) {
+    double tprev[NT], tcur[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        tprev[nt] = 1.0;
+        tcur[nt] = sc[nt];
+#pragma unroll
+        for (int t = 0; t < TL; ++t) acc[nt][t] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
+    }
+    for (int s = 0; s < ks; ++s) {
+        double a[TL];
+#pragma unroll
+        for (int t = 0; t < TL; ++t) a[t] = fk[(size_t)(s * TL + t) * 64];
+        double bop[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bop[nt] = 0.0;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * s + jj;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                double q;
+                if (j == 0) q = 1.0;
+                else if (j == 1) q = sc[nt];
+                else {
+                    q = __builtin_fma(2.0 * sc[nt], tcur[nt], -tprev[nt]);
+                    tprev[nt] = tcur[nt];
+                    tcur[nt] = q;
+                }
+                if (j >= n) q = 0.0;
+                bop[nt] = (jj == g) ? q : bop[nt];
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < TL; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bop[nt], acc[nt][t], 0, 0, 0);
+    }
+}
+
+template <int R, int NT>
+__global__ void __launch_bounds__(256)
+k_tt_eval_wfirst(TTDims dims, TTWPlan plan, const double *__restrict__ img,
+                 const double *__restrict__ pts, double *__restrict__ out, long N) {
+    constexpr int TILES = R * R / 16 > 0 ? R * R / 16 : 1;
+    constexpr int RB = R / 4;                       // outputs b owned per lane group
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    const int c16 = lane & 15;
+    const int d = dims.d;
+    // the packed cores are loaded ONCE per workgroup; the workgroup then walks over many
+    // batches of 4 x 16*NT points (grid-stride), so this prologue is amortised
+    for (int i = threadIdx.x; i < plan.total; i += 256) lds[i] = img[i];
+    __syncthreads();
+    double *xs = lds + plan.total + (size_t)wave * (16 * NT) * d;
+    const long nbatch = (N + 4 * 16 * NT - 1) / (4 * 16 * NT);
+  for (long batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const long base = (batch * 4 + wave) * (16 * NT);
+    {   // the wave's query rows: one contiguous, coalesced block copy into its own LDS slice
+        // (wave-private: LDS operations of one wave execute in order, no barrier needed)
+        const long first = base * d;
+        const long avail = (N - base) * (long)d;
+        const int cnt = 16 * NT * d;
+        for (int i = lane; i < cnt; i += 64) xs[i] = (i < avail) ? pts[first + i] : 0.0;
+    }
+
+    double v[NT][R];       // full left vector, replicated in the four lane groups
+    double vown[NT][RB];   // the entries a = 4 bi + g this lane group owns
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+        for (int a = 0; a < R; ++a) v[nt][a] = 0.0;
+#pragma unroll
+        for (int bi = 0; bi < RB; ++bi) vown[nt][bi] = 0.0;
+        v[nt][0] = 1.0;
+        vown[nt][0] = (g == 0) ? 1.0 : 0.0;
+    }
+
+    // fold W into v: v'[b] = sum_a v[a] W[(a,b)] for the b this lane group owns, then one
+    // shuffle per b re-assembles v' in every lane
+    auto fold = [&](auto &acc, auto tl_tag) {
+        constexpr int TL = decltype(tl_tag)::value;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double pb[RB];
+#pragma unroll
+            for (int bi = 0; bi < RB; ++bi) pb[bi] = 0.0;
+#pragma unroll
+            for (int t = 0; t < TL; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int u = 4 * t + i;
+                    pb[u % RB] = __builtin_fma(v[nt][u / RB], acc[nt][t][i], pb[u % RB]);
+                }
+#pragma unroll
+            for (int b = 0; b < R; ++b) v[nt][b] = __shfl(pb[b >> 2], ((b & 3) << 4) | c16, 64);
+#pragma unroll
+            for (int bi = 0; bi < RB; ++bi) vown[nt][bi] = pb[bi];
+        }
+    };
+
+    if (d > 1) {   // dimension 0 (left rank 1): rows a = 0 only -> tiles covering R rows
+        constexpr int TL0 = (R + 15) / 16;
+        double sc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double x = xs[(16 * nt + c16) * d + dims.col[0]];
+            sc[nt] = 2.0 * (x - dims.lo[0]) / (dims.hi[0] - dims.lo[0]) - 1.0;
+        }
+        pcx_d4 acc[NT][TL0];
+        tt_w_gemm<TL0, NT>(lds + plan.lds_off[0] + lane, dims.n[0], plan.ks[0], g, sc, acc);
+        fold(acc, std::integral_constant<int, TL0>{});
+    }
+    for (int k = 1; k < d - 1; ++k) {
+        const double lo = dims.lo[k], hi = dims.hi[k];
+        double sc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double x = xs[(16 * nt + c16) * d + dims.col[k]];
+            sc[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;
+        }
+        pcx_d4 acc[NT][TILES];
+        tt_w_gemm<TILES, NT>(lds + plan.lds_off[k] + lane, dims.n[k], plan.ks[k], g, sc, acc);
+        fold(acc, std::integral_constant<int, TILES>{});
+    }
+
+    // last dimension: y = sum_a v[a] * sum_j T_j(s) G[a][j]; lane group g takes a = g, g+4, ...
+    {
+        const int k = d - 1;
+        const int n = dims.n[k];
+        const double lo = dims.lo[k], hi = dims.hi[k];
+        const double *gl = lds + plan.lds_off[k];
+        const int rl = plan.rl_last;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            long p = base + 16 * nt + c16;
+            double x = xs[(16 * nt + c16) * d + dims.col[k]];
+            double sc = 2.0 * (x - lo) / (hi - lo) - 1.0;
+            double w[RB];
+#pragma unroll
+            for (int bi = 0; bi < RB; ++bi) w[bi] = 0.0;
+            double tp = 1.0, tc = sc;
+            for (int j = 0; j < n; ++j) {
+                double q;
+                if (j == 0) q = 1.0;
+                else if (j == 1) q = sc;
+                else { q = __builtin_fma(2.0 * sc, tc, -tp); tp = tc; tc = q; }
+#pragma unroll
+                for (int bi = 0; bi < RB; ++bi) {
+                    int a = 4 * bi + g;
+                    double gv = (a < rl) ? gl[a * n + j] : 0.0;
+                    w[bi] = __builtin_fma(q, gv, w[bi]);
+                }
+            }
+            double y = 0.0;
+#pragma unroll
+            for (int bi = 0; bi < RB; ++bi) y = __builtin_fma(vown[nt][bi], w[bi], y);
+            y += __shfl_xor(y, 16, 64);
+            y += __shfl_xor(y, 32, 64);
+            if (g == 0 && p < N) out[p] = y;
+        }
+    }
+  }   // batch loop
 }

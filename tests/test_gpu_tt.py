@@ -66,6 +66,32 @@ def test_eval_batch_rank16_10d_and_dim_order():
     assert abs(v[1] - (ttp.eval(up) - ttp.eval(dn)) / (2 * h)) < 1e-9
 
 
+def _set_tt_kernel(tt, variant):
+    t = tt._dev()
+    _lib.check(t.lib.pcx_tt_set_kernel(t.handle, variant), t.lib)
+
+
+def test_both_tt_kernel_forms_agree_with_reference():
+    """Ranks <= 12 have two kernels: the direct (node, rank)-GEMM form and the small-rank
+    "W first" form (auto picks the latter).  Both must match the reference."""
+    g = golden("g4_tt_bs5d")
+    for mr in (8, 15):
+        tt = ChebyshevTT.from_coeff_cores(_cores(g, f"r{mr}_", 5), F.BS5_DOMAIN)
+        for variant in (1, 2, 0):
+            _set_tt_kernel(tt, variant)
+            assert_parity(tt.eval_batch(g["points"]), g[f"r{mr}_eval"], 1e-12, f"TT r{mr} variant {variant}")
+    g = golden("g5b_tt_mixed")
+    dom = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
+    tt = ChebyshevTT.from_coeff_cores(_cores(g, "", 4), dom)
+    for variant in (1, 2):
+        _set_tt_kernel(tt, variant)
+        assert_parity(tt.eval_batch(g["points"]), g["out"], 1e-12, f"mixed variant {variant}")
+    g = golden("g5_tt_rank16")
+    tt16 = ChebyshevTT.from_coeff_cores(_cores(g, "", 10), [[-1.0, 1.0]] * 10)
+    t = tt16._dev()
+    assert t.lib.pcx_tt_set_kernel(t.handle, 2) == _lib.PCX_ERR_UNSUPPORTED     # rank 16 > 12
+
+
 def test_eval_batch_mixed_ranks_and_domains():
     g = golden("g5b_tt_mixed")
     dom = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
@@ -74,7 +100,9 @@ def test_eval_batch_mixed_ranks_and_domains():
 
 
 @pytest.mark.parametrize("ranks,n", [([1, 20, 24, 1], [5, 6, 4]), ([1, 33, 40, 64, 1], [3, 4, 3, 5]),
-                                     ([1, 1, 1], [9, 2]), ([1, 17, 1], [1, 8])])
+                                     ([1, 1, 1], [9, 2]), ([1, 17, 1], [1, 8]), ([1, 1], [13]),
+                                     ([1, 4, 3, 1], [7, 2, 33]), ([1, 9, 12, 5, 1], [6, 11, 4, 9]),
+                                     ([1, 2, 2, 2, 2, 2, 2, 1], [4] * 7)])
 def test_rank_classes_against_oracle(oracle_mod, ranks, n):
     rng = np.random.default_rng(sum(ranks))
     d = len(n)
