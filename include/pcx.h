@@ -75,6 +75,14 @@ int pcx_bary_create(int device, int d, const int32_t *n_nodes, const double *nod
                     pcx_bary **out);
 int pcx_bary_destroy(pcx_bary *h);
 
+/* Load a ChebyshevApproximation from a .pcb v1 file (reference _binary.py:208-283;
+ * examples/binary_reader/reader.c there is the reference's C reader) straight into a
+ * device handle.  Nodes / weights / differentiation matrices are rebuilt on the host
+ * with the formulas of barycentric.py:440-452, :30-49, :52-77.  For C/C++ callers.    */
+int pcx_bary_create_from_pcb(int device, const char *path, pcx_bary **out);
+/* Shape of a handle: d (may be NULL) and n_nodes (PCX_MAX_DIMS ints, may be NULL).   */
+int pcx_bary_shape(pcx_bary *h, int32_t *d_out, int32_t *n_nodes_out);
+
 /* vectorized_eval_batch (barycentric.py:992-1047): _apply_derivative_passes
  * (:951-990) once for `deriv` (d orders, NULL = all zero; cached per handle), then per
  * point the exact-node test |x - node| < 1e-14 / (T . w/diff) / sum(w/diff) reduction

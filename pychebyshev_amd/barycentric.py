@@ -520,29 +520,39 @@ class ChebyshevApproximation:
         self._device_index = None
 
     def save(self, path, format: str = "pickle") -> None:
-        """Pickle persistence (reference barycentric.py:1576-1625).  ``format='binary'``
-        (.pcb) is the next row of the build plan and not implemented yet."""
+        """Persist the built interpolant (reference barycentric.py:1576-1625): pickle by
+        default, or the portable ``.pcb`` layout with ``format='binary'``."""
         if self.tensor_values is None:
             raise RuntimeError("Cannot save an unbuilt ChebyshevApproximation. Call build() first.")
         if format == "pickle":
             with open(path, "wb") as f:
                 pickle.dump(self, f, protocol=pickle.HIGHEST_PROTOCOL)
         elif format == "binary":
-            raise NotImplementedError(".pcb binary persistence is not implemented in this build yet")
+            from . import _binary
+            with open(path, "wb") as f:
+                _binary.write_approx(f, self)
         else:
             raise ValueError(f"format must be 'pickle' or 'binary', got {format!r}")
 
     @classmethod
     def load(cls, path) -> "ChebyshevApproximation":
-        with open(path, "rb") as f:
-            head = f.read(4)
-        if head == b"PCB\x00":
-            raise NotImplementedError(".pcb binary persistence is not implemented in this build yet")
+        """Load a saved interpolant; ``.pcb`` files are recognised by their magic bytes
+        (reference barycentric.py:1627-1664)."""
+        from . import _binary
+        if _binary.detect_format(path) == "binary":
+            with open(path, "rb") as f:
+                return _binary.read_approx(f)
         with open(path, "rb") as f:
             obj = pickle.load(f)  # noqa: S301 - same trust model as the reference
         if not isinstance(obj, cls):
             raise TypeError(f"Expected a {cls.__name__} instance, got {type(obj).__name__}")
         return obj
+
+    @staticmethod
+    def peek_format_version(filename) -> int:
+        """Major version of a ``.pcb`` file without reading its body."""
+        from . import _binary
+        return _binary.peek_format_version(filename)
 
     # ---------------------------------------------------------------- printing
     def __repr__(self) -> str:

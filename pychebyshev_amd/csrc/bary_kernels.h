@@ -90,26 +90,38 @@ __device__ __forceinline__ double code_weight(unsigned code, const double *bw_co
 }
 
 // ---------------------------------------------------------------------------------
-// K1+K2 fused, MFMA form.  One wave owns PW = 16*NT query points for the whole kernel.
+// K1+K2 fused, MFMA form.  One wave owns PW = 16*NT query points.
 //
 //   prologue  weights of every dimension for the wave's points -> LDS table
 //             bw[row][point], rows = concatenated dims + one row of ones;
 //             B operands  B[nt][s] (lane l: k = 4s + (l>>4), point 16nt + (l&15))
 //             = product of the tail-dim weights named by kcode[k], kept in VGPRs.
-//   main      for each row tile t: acc[nt] = sum_s mfma(A = frag[t][s], B[nt][s]);
-//             D layout: lane l, reg j holds row (l>>4) + 4j, column (point) l & 15.
-//   epilogue  sum[nt] += acc[nt][j] * (product of head-dim weights named by
-//             rowcode[16t + (l>>4) + 4j]); finally add the four lane groups.
+//   main      row tiles are walked in CHUNKS of PCX_CHUNK_TILES; for each tile t:
+//             acc[nt] = sum_s mfma(A = frag[t][s], B[nt][s]);
+//             D layout: lane l, reg j holds row (l>>4) + 4j, column (point) l & 15;
+//             cs[nt] += acc[nt][j] * (head-dim weight product named by rowcode[...]).
+//   every PCX_CHUNK_TILES tiles the per-lane chunk sum is added to the per-lane total.
+//
+// Summation order is FIXED by the chunking, not by the launch geometry: per lane group g
+//   s_g = ((cs_0 + cs_1) + cs_2) + ...  over the chunks, then y = (s_0 + s_1) + (s_2 + s_3).
+// grid.y = 1: one workgroup walks all chunks, adds the lane groups by two shuffles, stores y.
+// grid.y > 1 ("split" launches for small batches): block y handles chunks
+//   [y*cps, (y+1)*cps) and stores each per-lane chunk sum to partial[z][chunk][g][p];
+//   k_bary_reduce then performs the same additions in the same order -> results are
+//   bit-identical for every batch size.
+// grid.z = number of derivative specs evaluated in this launch (frag_tab[z]).
 //
 // 256 threads = 4 waves; dynamic LDS = 4 * (sum_n + 1) * PW * 8 bytes.
 // ---------------------------------------------------------------------------------
+#define PCX_CHUNK_TILES 4
+
 template <int KS, int NT>
 __global__ void __launch_bounds__(256, 2)
 k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
-            const double *__restrict__ wts, const double *__restrict__ frag,
+            const double *__restrict__ wts, const double *const *__restrict__ frag_tab,
             const unsigned *__restrict__ rowcode, const unsigned *__restrict__ kcode,
             const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
-            long ooff) {
+            long ooff, int chunks_per_split, double *__restrict__ partial) {
     static_assert(NT == 1 || NT == 2 || NT == 4, "PW must divide the wave");
     constexpr int PW = 16 * NT;
     constexpr int PH = 64 / PW;
@@ -120,6 +132,13 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     const int c = lane & 15;
     double *bw = lds + (size_t)wave * (dims.sum_n + 1) * PW;
     const long base = ((long)blockIdx.x * 4 + wave) * PW;
+    // a pointer loaded from memory is "generic" to the compiler (flat_load + combined
+    // vmcnt/lgkmcnt waits); it is known to be global memory, say so
+    typedef const double __attribute__((address_space(1))) *gptr_t;
+    const gptr_t frag = (gptr_t)frag_tab[blockIdx.z];
+    const int nchunks = (plan.MT + PCX_CHUNK_TILES - 1) / PCX_CHUNK_TILES;
+    const int ch0 = blockIdx.y * chunks_per_split;
+    const int ch1 = (ch0 + chunks_per_split < nchunks) ? ch0 + chunks_per_split : nchunks;
 
     // ---- prologue 1: barycentric weights (lane -> point lane % PW, dims strided by PH)
     {
@@ -146,12 +165,16 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bw + 16 * nt + c, PW);
     }
 
-    // ---- main loop over row tiles
-    double sum[NT];
+    // ---- main loop over row tiles; every PCX_CHUNK_TILES tiles the per-lane chunk sum cs
+    //      is folded into the per-lane total (or stored, in a split launch)
+    double total[NT], cs[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) sum[nt] = 0.0;
-    const double *tf = frag + lane;
-    for (int t = 0; t < plan.MT; ++t) {
+    for (int nt = 0; nt < NT; ++nt) { total[nt] = 0.0; cs[nt] = 0.0; }
+    const gptr_t tf = frag + lane;
+    const int t_begin = ch0 * PCX_CHUNK_TILES;
+    const int t_end = (ch1 * PCX_CHUNK_TILES < plan.MT) ? ch1 * PCX_CHUNK_TILES : plan.MT;
+    const bool split = gridDim.y > 1;
+    for (int t = t_begin; t < t_end; ++t) {
         double w[NT][4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -162,7 +185,7 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         pcx_d4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
-        const double *tt = tf + (size_t)t * KS * 64;
+        const gptr_t tt = tf + (size_t)t * KS * 64;
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
             double a = tt[s * 64];
@@ -173,18 +196,53 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sum[nt] = __builtin_fma(acc[nt][j], w[nt][j], sum[nt]);
+            for (int j = 0; j < 4; ++j) cs[nt] = __builtin_fma(acc[nt][j], w[nt][j], cs[nt]);
+        const bool chunk_end = ((t + 1) % PCX_CHUNK_TILES == 0) || (t + 1 == plan.MT);
+        if (chunk_end) {
+            if (split) {
+                const int ch = t / PCX_CHUNK_TILES;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    long pidx = base + 16 * nt + c;
+                    if (pidx < N)
+                        partial[(((size_t)blockIdx.z * nchunks + ch) * 4 + g) * (size_t)N + pidx] = cs[nt];
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { total[nt] += cs[nt]; cs[nt] = 0.0; }
+        }
     }
 
-    // ---- reduce the four 16-lane groups and store
+    // ---- add the four 16-lane groups: lane group 0 ends with (s0 + s1) + (s2 + s3)
+    if (!split) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        double v = sum[nt];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        long pidx = base + 16 * nt + c;
-        if (g == 0 && pidx < N) out[pidx * ostride + ooff] = v;
+        for (int nt = 0; nt < NT; ++nt) {
+            double v = total[nt];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            long pidx = base + 16 * nt + c;
+            if (g == 0 && pidx < N) out[pidx * ostride + ooff + blockIdx.z] = v;
+        }
     }
+}
+
+// Finishes a split launch with exactly the additions of a non-split one: per lane group g
+// the chunk sums in chunk order, s_g = ((cs_0 + cs_1) + cs_2) + ..., then (s0 + s1) + (s2 + s3).
+// partial layout: [spec][chunk][group][point].
+__global__ void k_bary_reduce(const double *__restrict__ partial, double *__restrict__ out, long N,
+                              int nchunks, int nspec, long ostride, long ooff) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= N * nspec) return;
+    long p = idx % N;
+    int z = (int)(idx / N);
+    const double *src = partial + (size_t)z * nchunks * 4 * (size_t)N + p;
+    double sg[4];
+    for (int g = 0; g < 4; ++g) {
+        double t = 0.0;
+        for (int ch = 0; ch < nchunks; ++ch) t += src[((size_t)ch * 4 + g) * (size_t)N];
+        sg[g] = t;
+    }
+    out[p * ostride + ooff + z] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
 }
 
 // ---------------------------------------------------------------------------------

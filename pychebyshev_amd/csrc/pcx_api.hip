@@ -153,6 +153,7 @@ static const int64_t kChunkPoints = 1 << 23;
 struct DerivedTensor {
     double *plain = nullptr;  // C-order tensor after the derivative passes (prod n doubles)
     double *frag = nullptr;   // MFMA A-fragment packing of `plain` (MT*KS*64 doubles) or NULL
+    double **slot = nullptr;  // device table with the single entry `frag` (kernel's frag_tab)
 };
 
 struct pcx_bary {
@@ -172,7 +173,11 @@ struct pcx_bary {
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
     Scratch s_pts, s_out;
+    double **d_tab = nullptr;        // frag table for multi-spec launches (kMaxSpecs entries)
+    Scratch s_partial;               // per-chunk totals of split launches
 };
+
+static const int kMaxSpecs = 64;
 
 static const int kKsList[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 31, 32};
 
@@ -217,7 +222,10 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     for (auto &kv : h->cache) {
         if (kv.second.plain) (void)hipFree(kv.second.plain);
         if (kv.second.frag) (void)hipFree(kv.second.frag);
+        if (kv.second.slot) (void)hipFree(kv.second.slot);
     }
+    (void)hipFree(h->d_tab);
+    h->s_partial.release();
     (void)hipFree(h->d_nodes); (void)hipFree(h->d_wts); (void)hipFree(h->d_diff);
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
     h->s_pts.release(); h->s_out.release();
@@ -235,6 +243,8 @@ static int bary_pack(pcx_bary *h, DerivedTensor &dt) {
     hipLaunchKernelGGL(k_pack_fragments, dim3(blocks), dim3(256), 0, h->stream, dt.plain, dt.frag,
                        p.M, p.K, p.MT, p.KS);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMalloc((void **)&dt.slot, sizeof(double *)));
+    HIP_TRY(hipMemcpy(dt.slot, &dt.frag, sizeof(double *), hipMemcpyHostToDevice));
     return PCX_OK;
 }
 
@@ -341,9 +351,87 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     rc = bary_pack(h, dt);
     if (rc) { (void)hipFree(dt.plain); pcx_bary_destroy(h); return rc; }
     h->cache[std::vector<int>(d, 0)] = dt;
+    CREATE_TRY(hipMalloc((void **)&h->d_tab, kMaxSpecs * sizeof(double *)));
     CREATE_TRY(hipStreamSynchronize(h->stream));
 #undef CREATE_TRY
     *out = h;
+    return PCX_OK;
+}
+
+// ---- .pcb loader (host-side parsing and grid metadata; no evaluation arithmetic) ------
+static void host_grid_metadata(double lo, double hi, int n, double *x, double *w, double *D) {
+    const double pi = 3.14159265358979323846;
+    for (int k = 0; k < n; ++k)   // numpy chebpts1: sin(0.5 pi / n * (-n + 1 + 2k)), ascending
+        x[k] = 0.5 * (lo + hi) + 0.5 * (hi - lo) * std::sin(0.5 * pi / n * (double)(-n + 1 + 2 * k));
+    std::sort(x, x + n);
+    for (int i = 0; i < n; ++i) {
+        double wi = 1.0;
+        for (int j = 0; j < n; ++j)
+            if (j != i) wi /= (x[i] - x[j]);
+        w[i] = wi;
+    }
+    for (int i = 0; i < n; ++i) {
+        double rowsum = 0.0;
+        for (int j = 0; j < n; ++j) {
+            double v = (i == j) ? 0.0 : w[j] / ((x[i] - x[j]) * w[i]);
+            D[(size_t)i * n + j] = v;
+            rowsum += v;
+        }
+        D[(size_t)i * n + i] = -rowsum;
+    }
+}
+
+extern "C" int pcx_bary_create_from_pcb(int device, const char *path, pcx_bary **out) {
+    if (!out) return fail(PCX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (!path) return fail(PCX_ERR_INVALID, "path is NULL");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(PCX_ERR_INVALID, "cannot open %s", path);
+    auto bail = [&](const char *why) { fclose(f); return fail(PCX_ERR_INVALID, "%s: %s", path, why); };
+    unsigned char head[12];
+    if (fread(head, 1, 12, f) != 12) return bail("shorter than the 12-byte .pcb header");
+    if (memcmp(head, "PCB\0", 4) != 0) return bail("not a PyChebyshev binary file (bad magic)");
+    if (head[4] != 1) return bail("unsupported .pcb major version");
+    if ((head[6] | (head[7] << 8)) != 1) return bail("class tag is not ChebyshevApproximation");
+    if (head[8] | head[9] | head[10] | head[11]) return bail("reserved header bytes nonzero");
+    uint32_t d = 0;
+    if (fread(&d, 4, 1, f) != 1) return bail("unexpected EOF reading num_dimensions");
+    if (d < 1 || d > PCX_MAX_DIMS) return bail("num_dimensions outside [1, 16]");
+    std::vector<double> lo(d), hi(d);
+    std::vector<uint32_t> nn(d);
+    if (fread(lo.data(), 8, d, f) != d || fread(hi.data(), 8, d, f) != d || fread(nn.data(), 4, d, f) != d)
+        return bail("unexpected EOF reading domain / n_nodes");
+    size_t total = 1, sum_n = 0, sum_n2 = 0;
+    std::vector<int32_t> n(d);
+    for (uint32_t k = 0; k < d; ++k) {
+        if (!(lo[k] < hi[k])) return bail("domain lo must be < hi");
+        if (nn[k] < 1 || nn[k] > 4096) return bail("n_nodes outside [1, 4096]");
+        n[k] = (int32_t)nn[k];
+        total *= nn[k];
+        sum_n += nn[k];
+        sum_n2 += (size_t)nn[k] * nn[k];
+        if (total > ((size_t)1 << 33)) return bail("tensor larger than 2^33 elements");
+    }
+    std::vector<double> tensor(total);
+    if (fread(tensor.data(), 8, total, f) != total) return bail("unexpected EOF reading tensor_values");
+    fclose(f);
+    for (size_t i = 0; i < total; ++i)
+        if (!std::isfinite(tensor[i])) return fail(PCX_ERR_INVALID, "%s: tensor_values contains NaN or Inf", path);
+    std::vector<double> nodes(sum_n), wts(sum_n), diff(sum_n2);
+    size_t o1 = 0, o2 = 0;
+    for (uint32_t k = 0; k < d; ++k) {
+        host_grid_metadata(lo[k], hi[k], n[k], nodes.data() + o1, wts.data() + o1, diff.data() + o2);
+        o1 += n[k];
+        o2 += (size_t)n[k] * n[k];
+    }
+    return pcx_bary_create(device, (int)d, n.data(), nodes.data(), wts.data(), diff.data(), tensor.data(), out);
+}
+
+extern "C" int pcx_bary_shape(pcx_bary *h, int32_t *d_out, int32_t *n_nodes_out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (d_out) *d_out = h->dims.d;
+    if (n_nodes_out)
+        for (int k = 0; k < PCX_MAX_DIMS; ++k) n_nodes_out[k] = k < h->dims.d ? h->dims.n[k] : 0;
     return PCX_OK;
 }
 
@@ -390,30 +478,52 @@ static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **ou
     return PCX_OK;
 }
 
+// One MFMA launch for m specs (frag_tab: device table of m fragment pointers).  Small
+// batches are split over grid.y (chunks of row tiles) so that a handful of points still
+// uses the whole chip; the per-chunk totals are then added by k_bary_reduce in the fixed
+// chunk order, which makes every result independent of the batch size.
 template <int KS, int NT>
-static int launch_mfma_t(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
-                         double *d_out, long ostride, long ooff, hipStream_t st) {
+static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
+                         double *d_out, long ostride, long ooff, hipStream_t st, bool allow_split) {
     size_t lds = mfma_lds_bytes(h->dims, NT);
     auto kern = k_bary_mfma<KS, NT>;
-    static thread_local size_t set_for = 0;
-    if (lds > 64 * 1024 || set_for < lds) {
+    if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        set_for = lds;
-    }
     long per_wg = 4L * 16 * NT;
     long blocks = (N + per_wg - 1) / per_wg;
     if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->plan, h->d_nodes,
-                       h->d_wts, dt.frag, h->d_rowcode, h->d_kcode, d_pts, d_out, N, ostride, ooff);
+    int nchunks = (h->plan.MT + PCX_CHUNK_TILES - 1) / PCX_CHUNK_TILES;
+    int nsplit = 1, cps = nchunks;
+    const long want = 512;   // workgroups that fill 256 CUs at two per CU
+    if (allow_split && blocks * m < want && nchunks > 1) {
+        nsplit = (int)std::min<long>(nchunks, (want + blocks * m - 1) / (blocks * m));
+        cps = (nchunks + nsplit - 1) / nsplit;
+        nsplit = (nchunks + cps - 1) / cps;
+    }
+    double *partial = nullptr;
+    if (nsplit > 1) {
+        int rc = h->s_partial.reserve((size_t)m * nchunks * 4 * (size_t)N * sizeof(double));
+        if (rc) return rc;
+        partial = (double *)h->s_partial.ptr;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit, (unsigned)m), dim3(256), lds, st,
+                       h->dims, h->plan, h->d_nodes, h->d_wts, frag_tab, h->d_rowcode, h->d_kcode, d_pts,
+                       d_out, N, ostride, ooff, cps, partial);
     HIP_TRY(hipGetLastError());
+    if (nsplit > 1) {
+        long cnt = N * m;
+        hipLaunchKernelGGL(k_bary_reduce, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, partial, d_out,
+                           N, nchunks, m, ostride, ooff);
+        HIP_TRY(hipGetLastError());
+    }
     return PCX_OK;
 }
 
 template <int NT>
-static int launch_mfma_nt(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
-                          double *d_out, long ostride, long ooff, hipStream_t st) {
+static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
+                          double *d_out, long ostride, long ooff, hipStream_t st, bool allow_split) {
     switch (h->plan.KS) {
-#define CASE_KS(v) case v: return launch_mfma_t<v, NT>(h, dt, d_pts, N, d_out, ostride, ooff, st);
+#define CASE_KS(v) case v: return launch_mfma_t<v, NT>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, allow_split);
         CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(6) CASE_KS(8) CASE_KS(12) CASE_KS(16)
         CASE_KS(20) CASE_KS(24) CASE_KS(28) CASE_KS(31) CASE_KS(32)
 #undef CASE_KS
@@ -436,17 +546,26 @@ static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts
     return PCX_OK;
 }
 
-static int bary_launch(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
-                       double *d_out, long ostride, long ooff, hipStream_t st) {
+// Evaluate m specs (dts[0..m)) at N device-resident points; out[p*ostride + ooff + s].
+// frag_tab is a device table holding the m fragment pointers (MFMA path only).
+static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const double *const *frag_tab,
+                       const double *d_pts, long N, double *d_out, long ostride, long ooff,
+                       hipStream_t st, bool allow_split) {
     if (N == 0) return PCX_OK;
     int variant = h->variant;
     if (variant == 0) variant = h->mfma_ok ? 2 : 1;
     if (variant == 2) {
         if (!h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
-        return h->nt == 2 ? launch_mfma_nt<2>(h, dt, d_pts, N, d_out, ostride, ooff, st)
-                          : launch_mfma_nt<1>(h, dt, d_pts, N, d_out, ostride, ooff, st);
+        // two column tiles per wave for throughput; one when the batch cannot fill the chip
+        int nt = (N >= 65536) ? h->nt : 1;
+        return nt == 2 ? launch_mfma_nt<2>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, allow_split)
+                       : launch_mfma_nt<1>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, allow_split);
     }
-    return launch_rows(h, dt, d_pts, N, d_out, ostride, ooff, st);
+    for (int s = 0; s < m; ++s) {
+        int rc = launch_rows(h, *dts[s], d_pts, N, d_out, ostride, ooff + s, st);
+        if (rc) return rc;
+    }
+    return PCX_OK;
 }
 
 extern "C" int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t N,
@@ -460,13 +579,15 @@ extern "C" int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t
     int rc = bary_get_tensor(h, deriv, &dt);
     if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
-    return bary_launch(h, *dt, d_pts, (long)N, d_out, 1, 0, st);
+    // split launches share the handle's scratch: only on the handle's own stream
+    return bary_launch(h, &dt, 1, dt->slot, d_pts, (long)N, d_out, 1, 0, st, st == h->stream);
 }
 
 static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs, int m,
                           double *out) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
     if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (m > kMaxSpecs) return fail(PCX_ERR_UNSUPPORTED, "more than %d derivative specs in one call", kMaxSpecs);
     if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
@@ -476,6 +597,13 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         int rc = bary_get_tensor(h, derivs ? derivs + (size_t)s * d : nullptr, &dts[s]);
         if (rc) return rc;
     }
+    const double *const *frag_tab = dts[0]->slot;
+    if (m > 1 && h->mfma_ok) {
+        std::vector<double *> tab(m);
+        for (int s = 0; s < m; ++s) tab[s] = dts[s]->frag;
+        HIP_TRY(hipMemcpy(h->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+        frag_tab = h->d_tab;
+    }
     for (int64_t start = 0; start < N; start += kChunkPoints) {
         long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
         int rc = h->s_pts.reserve((size_t)cnt * d * sizeof(double));
@@ -484,10 +612,8 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         if (rc) return rc;
         double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
         HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        for (int s = 0; s < m; ++s) {
-            rc = bary_launch(h, *dts[s], dp, cnt, dout, m, s, h->stream);
-            if (rc) return rc;
-        }
+        rc = bary_launch(h, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, h->stream, true);
+        if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }

@@ -1,0 +1,133 @@
+""".pcb binary format: byte layout, round trips, corruption
+handling (CPU), and evaluation of models loaded from the reference's own fixtures (GPU)."""
+import ctypes
+import io
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_parity, golden
+from pychebyshev_amd import ChebyshevApproximation, _binary, _lib
+
+
+def _xy():
+    c = ChebyshevApproximation(lambda pt, _: pt[0] + pt[1], 2, [(-1.0, 1.0), (-1.0, 1.0)], [3, 3])
+    c.build(verbose=False)
+    return c
+
+
+def _bytes(c):
+    buf = io.BytesIO()
+    _binary.write_approx(buf, c)
+    return buf.getvalue()
+
+
+def test_exact_byte_layout_of_the_3x3_model():
+    """The reference's golden layout (test_binary_format.py:565-600 there): 128 bytes."""
+    c = _xy()
+    data = _bytes(c)
+    assert len(data) == 128
+    assert data[:4] == b"PCB\x00" and data[4] == 1 and data[5] == 0
+    assert data[6:8] == struct.pack("<H", 1) and data[8:12] == b"\x00" * 4
+    assert struct.unpack_from("<I", data, 12)[0] == 2
+    assert np.array_equal(np.frombuffer(data[16:32], "<f8"), [-1.0, -1.0])
+    assert np.array_equal(np.frombuffer(data[32:48], "<f8"), [1.0, 1.0])
+    assert np.array_equal(np.frombuffer(data[48:56], "<u4"), [3, 3])
+    assert np.array_equal(np.frombuffer(data[56:128], "<f8").reshape(3, 3), c.tensor_values)
+
+
+def test_round_trips_and_reference_fixtures(tmp_path):
+    c = _xy()
+    data = _bytes(c)
+    back = _binary.read_approx(io.BytesIO(data))
+    assert _bytes(back) == data
+    assert back.function is None and back.n_nodes == [3, 3] and back.domain == [[-1.0, 1.0], [-1.0, 1.0]]
+    assert np.array_equal(back.tensor_values, c.tensor_values)
+    assert all(np.array_equal(a, b) for a, b in zip(back.nodes, c.nodes))
+    # save/load through the class API, auto-detected by magic
+    path = tmp_path / "m.pcb"
+    c.save(path, format="binary")
+    assert ChebyshevApproximation.peek_format_version(str(path)) == 1
+    assert _binary.detect_format(path) == "binary"
+    again = ChebyshevApproximation.load(path)
+    assert np.array_equal(again.tensor_values, c.tensor_values)
+    c.save(tmp_path / "m.pkl")
+    assert _binary.detect_format(tmp_path / "m.pkl") == "pickle"
+    # the reference's own fixture files re-serialise to identical bytes
+    for name, size in (("approx_2d_simple.pcb", 184), ("approx_5d_bs.pcb", 62324)):
+        raw = open(os.path.join(GOLDEN, name), "rb").read()
+        assert len(raw) == size
+        model = _binary.read_approx(io.BytesIO(raw))
+        assert _bytes(model) == raw
+    with pytest.raises(NotImplementedError):
+        c2 = _xy()
+        c2.additional_data = {"k": 1}
+        _bytes(c2)
+    with pytest.raises(RuntimeError):
+        _binary.write_approx(io.BytesIO(), ChebyshevApproximation(lambda p, _: 0.0, 1, [[0, 1]], [3]))
+
+
+def test_corrupt_files_are_rejected(tmp_path):
+    data = _bytes(_xy())
+    def rd(b):
+        return _binary.read_approx(io.BytesIO(b))
+    with pytest.raises(ValueError, match="bad magic"):
+        rd(b"XXXX" + data[4:])
+    with pytest.raises(ValueError, match="major version"):
+        rd(data[:4] + b"\x02" + data[5:])
+    with pytest.raises(ValueError, match="class_tag 2"):
+        rd(data[:6] + struct.pack("<H", 2) + data[8:])
+    with pytest.raises(ValueError, match="reserved"):
+        rd(data[:8] + b"\x01\x00\x00\x00" + data[12:])
+    with pytest.raises(ValueError, match="EOF"):
+        rd(data[:100])
+    with pytest.raises(ValueError, match="EOF"):
+        rd(data[:7])
+    with pytest.raises(ValueError, match="num_dimensions"):
+        rd(data[:12] + struct.pack("<I", 0) + data[16:])
+    bad_dom = bytearray(data)
+    bad_dom[16:24] = struct.pack("<d", 5.0)
+    with pytest.raises(ValueError, match="lo"):
+        rd(bytes(bad_dom))
+    short = tmp_path / "s.pcb"
+    short.write_bytes(b"PCB")
+    with pytest.raises(ValueError, match="shorter"):
+        _binary.peek_format_version(str(short))
+    other = tmp_path / "o.bin"
+    other.write_bytes(b"0123456789abcdef")
+    with pytest.raises(ValueError, match="magic mismatch"):
+        _binary.peek_format_version(str(other))
+
+
+@pytest.mark.gpu
+def test_models_loaded_from_pcb_evaluate_like_the_reference(tmp_path):
+    g = golden("g3_pcb")
+    c5 = ChebyshevApproximation.load(os.path.join(GOLDEN, "approx_5d_bs.pcb"))
+    assert_parity(c5.vectorized_eval_batch(g["p5"], [0] * 5), g["v5"], 1e-12, "pcb5")
+    c2 = ChebyshevApproximation.load(os.path.join(GOLDEN, "approx_2d_simple.pcb"))
+    assert_parity(c2.vectorized_eval_batch(g["p2"], [1, 1]), g["d2"], 1e-12, "pcb2", float("inf"))
+    # C entry point: file -> device handle without Python-side parsing
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    _lib.check(lib.pcx_bary_create_from_pcb(0, os.path.join(GOLDEN, "approx_5d_bs.pcb").encode(), ctypes.byref(h)), lib)
+    try:
+        d = ctypes.c_int32()
+        n = _lib.i32(np.zeros(16))
+        _lib.check(lib.pcx_bary_shape(h, ctypes.byref(d), _lib.p_i32(n)), lib)
+        assert d.value == 5 and list(n[:6]) == [6, 6, 6, 6, 6, 0]
+        pts = _lib.f64(g["p5"])
+        out = np.empty(len(pts))
+        _lib.check(lib.pcx_bary_eval_batch(h, _lib.p_f64(pts), len(pts), None, _lib.p_f64(out)), lib)
+        assert_parity(out, g["v5"], 1e-12, "pcb5 via pcx_bary_create_from_pcb")
+        spec = _lib.i32([0, 1, 0, 0, 1])
+        _lib.check(lib.pcx_bary_eval_batch(h, _lib.p_f64(pts), len(pts), _lib.p_i32(spec), _lib.p_f64(out)), lib)
+        assert_parity(out, g["d5"], 1e-12, "pcb5 deriv via C loader", float("inf"))
+    finally:
+        lib.pcx_bary_destroy(h)
+    bad = tmp_path / "bad.pcb"
+    bad.write_bytes(b"PCB\x00\x01\x00\x02\x00" + b"\x00" * 40)
+    assert lib.pcx_bary_create_from_pcb(0, str(bad).encode(), ctypes.byref(h)) == _lib.PCX_ERR_INVALID
+    assert b"class tag" in lib.pcx_last_error()
+    assert lib.pcx_bary_create_from_pcb(0, b"/nonexistent/x.pcb", ctypes.byref(h)) == _lib.PCX_ERR_INVALID

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Single-query latency of the drop-in classes (the reference publishes 0.065 ms/query for
+vectorized_eval and TT eval, 0.29 ms for price + 5 Greeks via vectorized_eval_multi)."""
+import os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import functions as F
+from pychebyshev_amd import ChebyshevApproximation, ChebyshevTT
+
+g = np.load(os.path.join(ROOT, "tests", "golden", "g2_bs5d.npz"))
+cheb = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES)
+g4 = np.load(os.path.join(ROOT, "tests", "golden", "g4_tt_bs5d.npz"))
+tt = ChebyshevTT.from_coeff_cores([g4[f"r8_core{k}"] for k in range(5)], F.BS5_DOMAIN)
+pts = F.bs5_query_points(1000, seed=99)
+specs = F.GREEK_SPECS_5D[:6]
+
+def bench(name, fn, n=1000):
+    fn(0)
+    t0 = time.perf_counter()
+    for i in range(n):
+        fn(i)
+    dt = (time.perf_counter() - t0) / n
+    print(f"{name:46s} {dt * 1e3:8.4f} ms/query")
+
+bench("ChebyshevApproximation.vectorized_eval price", lambda i: cheb.vectorized_eval(pts[i].tolist(), [0, 0, 0, 0, 0]))
+bench("ChebyshevApproximation.vectorized_eval delta", lambda i: cheb.vectorized_eval(pts[i].tolist(), [1, 0, 0, 0, 0]))
+bench("vectorized_eval_multi price + 5 Greeks", lambda i: cheb.vectorized_eval_multi(pts[i].tolist(), specs))
+bench("ChebyshevTT.eval", lambda i: tt.eval(pts[i].tolist()))
+bench("ChebyshevTT.eval_multi value + delta + gamma", lambda i: tt.eval_multi(pts[i].tolist(), [[0] * 5, [1, 0, 0, 0, 0], [2, 0, 0, 0, 0]]))
+for n in (1, 10, 100, 1000, 10_000, 100_000, 1_000_000):
+    p = F.bs5_query_points(n, seed=5)
+    cheb.vectorized_eval_batch(p, [0] * 5)
+    reps = max(3, min(200, int(2e5 / n)))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cheb.vectorized_eval_batch(p, [0] * 5)
+    dt = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        tt.eval_batch(p)
+    dt2 = (time.perf_counter() - t0) / reps
+    print(f"host-pointer batch N={n:8d}: barycentric {dt * 1e3:9.4f} ms ({n / dt:10.3e} pts/s)   TT {dt2 * 1e3:9.4f} ms ({n / dt2:10.3e} pts/s)")
