@@ -834,7 +834,7 @@ static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipS
     if (h->variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
     if (h->wR && h->variant != 1) {
         if (h->wR == 4) return tt_launch_wfirst<4, 4>(h, d_pts, N, d_out, st);
-        if (h->wR == 8) return tt_launch_wfirst<8, 2>(h, d_pts, N, d_out, st);
+        if (h->wR == 8) return tt_launch_wfirst<8, 1>(h, d_pts, N, d_out, st);
         return tt_launch_wfirst<12, 1>(h, d_pts, N, d_out, st);
     }
     auto go = [&](auto kern, int nt) -> int {
