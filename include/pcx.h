@@ -46,6 +46,7 @@ extern "C" {
 
 typedef struct pcx_bary pcx_bary; /* device-resident ChebyshevApproximation state */
 typedef struct pcx_tt pcx_tt;     /* device-resident ChebyshevTT coefficient cores */
+typedef struct pcx_spline pcx_spline; /* knots + piece handles of a ChebyshevSpline   */
 
 /* ---- library / device ------------------------------------------------------ */
 int pcx_abi_version(void);
@@ -107,6 +108,23 @@ int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, double *tensor
 int pcx_bary_set_kernel(pcx_bary *h, int variant);
 int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
 int pcx_bary_stream(pcx_bary *h, void **stream);
+
+/* ---- piecewise (spline) interpolant ---------------------------------------- */
+/* ChebyshevSpline (spline.py:35-700): per-dimension sorted interior knots (concatenated)
+ * and one pcx_bary handle per piece in C order over the per-dimension intervals
+ * (n_pieces = prod(n_knots[k] + 1)).  The spline handle BORROWS the piece handles: they
+ * must outlive it and live on the same device.                                        */
+int pcx_spline_create(int device, int d, const int32_t *n_knots, const double *knots_cat,
+                      pcx_bary *const *pieces, int n_pieces, pcx_spline **out);
+int pcx_spline_destroy(pcx_spline *h);
+/* eval_batch (spline.py:633-700): piece = searchsorted(knots, x, side='right') clipped,
+ * points bucketed per piece on the device, one barycentric launch per non-empty piece. */
+int pcx_spline_eval_batch(pcx_spline *h, const double *pts, int64_t N, const int32_t *deriv,
+                          double *out);
+int pcx_spline_eval_multi_batch(pcx_spline *h, const double *pts, int64_t N, const int32_t *derivs,
+                                int m, double *out);
+/* The piece index of every point (spline.py:414-446, _find_piece) -- for tests/tools.  */
+int pcx_spline_piece_ids(pcx_spline *h, const double *pts, int64_t N, int32_t *ids_out);
 
 /* ---- tensor-train interpolant ---------------------------------------------- */
 /* State of ChebyshevTT (tensor_train.py:1117-1138): Chebyshev COEFFICIENT cores

@@ -437,6 +437,32 @@ def tt_eval_multi(coeff_cores, domain, point, derivative_orders, dim_order=None)
     return out
 
 
+# ----------------------------------------------------------------------------
+# Piecewise interpolant (spline.py:414-446, :633-700)
+# ----------------------------------------------------------------------------
+
+def spline_piece_ids(knots, shape, pts) -> np.ndarray:
+    """Flat piece index per point: searchsorted(side='right') per dimension, clipped."""
+    pts = _f64(pts)
+    multi = np.zeros((pts.shape[0], len(shape)), dtype=np.int64)
+    for d, kn in enumerate(knots):
+        if len(kn) > 0:
+            multi[:, d] = np.clip(np.searchsorted(np.asarray(kn, dtype=float), pts[:, d], side="right"),
+                                  0, shape[d] - 1)
+    return np.ravel_multi_index(multi.T, shape)
+
+
+def spline_eval_batch(piece_models, knots, shape, pts, order=None) -> np.ndarray:
+    """eval_batch of a ChebyshevSpline given one BaryModel per piece (C order)."""
+    pts = _f64(pts)
+    out = np.empty(pts.shape[0])
+    ids = spline_piece_ids(knots, shape, pts)
+    for pid in np.unique(ids):
+        mask = ids == pid
+        out[mask] = bary_eval_batch(piece_models[int(pid)], pts[mask], order)
+    return out
+
+
 def num_threads() -> int:
     return int(_lib().pcxo_num_threads())
 

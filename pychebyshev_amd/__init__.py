@@ -1,7 +1,8 @@
 """pychebyshev_amd -- MI355X-native drop-in for PyChebyshev's batched-evaluation hot path.
 
 Exports the reference's public names for that path (``ChebyshevApproximation``,
-``ChebyshevTT`` and the typed helpers ``Domain`` / ``Ns`` / ``SpecialPoints``,
+``ChebyshevTT``, ``ChebyshevSpline`` -- the direct caller of the barycentric path -- and the
+typed helpers ``Domain`` / ``Ns`` / ``SpecialPoints``,
 reference ``__init__.py:28-78``).  Evaluation runs in hand-written HIP kernels behind a
 C ABI (``include/pcx.h`` -> ``libpcx_hip.so``); importing this package never touches
 the GPU, but every evaluation call does and raises if the library or a device is absent.
@@ -35,6 +36,8 @@ class SpecialPoints:
 
 
 from .barycentric import ChebyshevApproximation  # noqa: E402
+from .spline import ChebyshevSpline  # noqa: E402
 from .tensor_train import ChebyshevTT  # noqa: E402
 
-__all__ = ["ChebyshevApproximation", "ChebyshevTT", "Domain", "Ns", "SpecialPoints", "__version__"]
+__all__ = ["ChebyshevApproximation", "ChebyshevSpline", "ChebyshevTT", "Domain", "Ns", "SpecialPoints",
+           "__version__"]

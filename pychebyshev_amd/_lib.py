@@ -70,6 +70,11 @@ SIGNATURES = {
     "pcx_bary_set_kernel": (_I, [_V, _I]),
     "pcx_bary_kernel_info": (_I, [_V, c_i32p]),
     "pcx_bary_stream": (_I, [_V, c_vpp]),
+    "pcx_spline_create": (_I, [_I, _I, c_i32p, c_f64p, c_vpp, _I, c_vpp]),
+    "pcx_spline_destroy": (_I, [_V]),
+    "pcx_spline_eval_batch": (_I, [_V, c_f64p, _L, c_i32p, c_f64p]),
+    "pcx_spline_eval_multi_batch": (_I, [_V, c_f64p, _L, c_i32p, _I, c_f64p]),
+    "pcx_spline_piece_ids": (_I, [_V, c_f64p, _L, c_i32p]),
     "pcx_tt_create": (_I, [_I, _I, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p, c_i32p, c_vpp]),
     "pcx_tt_destroy": (_I, [_V]),
     "pcx_tt_eval_batch": (_I, [_V, c_f64p, _L, c_f64p]),

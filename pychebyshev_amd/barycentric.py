@@ -15,8 +15,9 @@ CPU fallback -- if the library or a device is missing the call raises.  Grid met
 (nodes, weights, differentiation matrices) is tiny, host-built once with NumPy exactly
 as the reference builds it, and copied to the device when the first evaluation happens.
 
-Out of scope in this tier (raise ``NotImplementedError``): error-threshold auto-N,
-``special_points`` with knots (spline dispatch), algebra/calculus/extrude/slice.
+``special_points`` with knots dispatch to :class:`pychebyshev_amd.spline.ChebyshevSpline` as in
+the reference.  Out of scope in this tier (raise ``NotImplementedError``): error-threshold
+auto-N, algebra/calculus/extrude/slice.
 """
 from __future__ import annotations
 
@@ -142,10 +143,15 @@ class ChebyshevApproximation:
                     raise ValueError(f"special_points[{d}] must be a list/tuple of floats, "
                                      f"got {type(knots).__name__}: {knots!r}")
             if any(len(knots) > 0 for knots in sp):
-                # the reference dispatches to ChebyshevSpline here (barycentric.py:321-338)
-                raise NotImplementedError(
-                    "special_points with knots dispatch to ChebyshevSpline in the reference; "
-                    "piecewise interpolants are outside this build's hot-path scope")
+                # kinks declared: hand over to the piecewise class, as the reference does
+                # (barycentric.py:321-338); its __init__ has already run when we return it
+                from .spline import ChebyshevSpline
+                dom, nn, _ = _unwrap_typed(domain, n_nodes, None)
+                return ChebyshevSpline(function, num_dimensions, dom, n_nodes=nn, knots=sp,
+                                       max_derivative_order=max_derivative_order,
+                                       error_threshold=error_threshold, max_n=max_n,
+                                       additional_data=additional_data, defer_build=defer_build,
+                                       n_workers=n_workers)
         return super().__new__(cls)
 
     def __init__(self, function: Callable, num_dimensions: int,

@@ -121,7 +121,10 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             const double *__restrict__ wts, const double *const *__restrict__ frag_tab,
             const unsigned *__restrict__ rowcode, const unsigned *__restrict__ kcode,
             const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
-            long ooff, int chunks_per_split, double *__restrict__ partial) {
+            long ooff, int chunks_per_split, double *__restrict__ partial,
+            const int *__restrict__ perm) {
+    // perm (optional): the launch covers the N rows perm[0..N) of pts/out (a bucket of a
+    // piecewise interpolant) instead of rows 0..N.
     static_assert(NT == 1 || NT == 2 || NT == 4, "PW must divide the wave");
     constexpr int PW = 16 * NT;
     constexpr int PH = 64 / PW;
@@ -146,9 +149,10 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         const int ph = lane / PW;
         const long pidx = base + pp;
         const bool valid = pidx < N;
+        const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
         for (int k = ph; k < dims.d; k += PH) {
             const double *nd = nodes + dims.off[k];
-            double x = valid ? pts[pidx * dims.d + k] : nd[0];
+            double x = valid ? pts[row * dims.d + k] : nd[0];
             bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + (size_t)dims.off[k] * PW + pp,
                             PW);
         }
@@ -221,7 +225,10 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             v += __shfl_xor(v, 16, 64);
             v += __shfl_xor(v, 32, 64);
             long pidx = base + 16 * nt + c;
-            if (g == 0 && pidx < N) out[pidx * ostride + ooff + blockIdx.z] = v;
+            if (g == 0 && pidx < N) {
+                long row = perm ? (long)perm[pidx] : pidx;
+                out[row * ostride + ooff + blockIdx.z] = v;
+            }
         }
     }
 }
@@ -230,7 +237,8 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
 // the chunk sums in chunk order, s_g = ((cs_0 + cs_1) + cs_2) + ..., then (s0 + s1) + (s2 + s3).
 // partial layout: [spec][chunk][group][point].
 __global__ void k_bary_reduce(const double *__restrict__ partial, double *__restrict__ out, long N,
-                              int nchunks, int nspec, long ostride, long ooff) {
+                              int nchunks, int nspec, long ostride, long ooff,
+                              const int *__restrict__ perm) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= N * nspec) return;
     long p = idx % N;
@@ -242,7 +250,8 @@ __global__ void k_bary_reduce(const double *__restrict__ partial, double *__rest
         for (int ch = 0; ch < nchunks; ++ch) t += src[((size_t)ch * 4 + g) * (size_t)N];
         sg[g] = t;
     }
-    out[p * ostride + ooff + z] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
+    long row = perm ? (long)perm[p] : p;
+    out[row * ostride + ooff + z] = (sg[0] + sg[1]) + (sg[2] + sg[3]);
 }
 
 // ---------------------------------------------------------------------------------
@@ -255,17 +264,18 @@ __global__ void __launch_bounds__(256)
 k_bary_rows(BaryDims dims, int LPP, const double *__restrict__ nodes,
             const double *__restrict__ wts, const double *__restrict__ T,
             const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
-            long ooff) {
+            long ooff, const int *__restrict__ perm) {
     extern __shared__ double lds[];
     const int ppw = 256 / LPP;                 // points per workgroup
     const int pl = threadIdx.x / LPP;          // local point
     const int sub = threadIdx.x % LPP;         // lane within the point's group
     const long pidx = (long)blockIdx.x * ppw + pl;
     const bool valid = pidx < N;
+    const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
     double *bw = lds + (size_t)pl * dims.sum_n;
     for (int k = sub; k < dims.d; k += LPP) {
         const double *nd = nodes + dims.off[k];
-        double x = valid ? pts[pidx * dims.d + k] : nd[0];
+        double x = valid ? pts[row * dims.d + k] : nd[0];
         bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + dims.off[k], 1);
     }
     __syncthreads();
@@ -290,5 +300,50 @@ k_bary_rows(BaryDims dims, int LPP, const double *__restrict__ nodes,
         acc = __builtin_fma(s, w, acc);
     }
     for (int o = LPP >> 1; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (sub == 0 && valid) out[pidx * ostride + ooff] = acc;
+    if (sub == 0 && valid) out[row * ostride + ooff] = acc;
+}
+
+// ---------------------------------------------------------------------------------
+// Piecewise interpolants (reference spline.py:633-700, ChebyshevSpline.eval_batch):
+// route every point to its piece, bucket the points, then run the barycentric kernel once
+// per non-empty piece on that piece's bucket (its `perm` argument).
+// ---------------------------------------------------------------------------------
+struct SplineDims {
+    int d;
+    int nknots[PCX_MAX_DIMS];   // knots per dimension
+    int koff[PCX_MAX_DIMS];     // offset of dimension k's knots in knots_cat
+    int shape[PCX_MAX_DIMS];    // pieces per dimension = nknots + 1
+};
+
+// piece index = ravel_multi_index(clip(searchsorted(knots_k, x_k, side='right'), 0, shape_k - 1)):
+// the number of knots <= x (a point exactly on a knot belongs to the piece on its right);
+// NaN sorts after every knot in NumPy, i.e. lands in the last piece.  Also builds the
+// per-piece histogram.
+__global__ void k_spline_piece_id(SplineDims sd, const double *__restrict__ knots,
+                                  const double *__restrict__ pts, long N, int *__restrict__ piece,
+                                  int *__restrict__ counts) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    int flat = 0;
+    for (int k = 0; k < sd.d; ++k) {
+        double x = pts[p * sd.d + k];
+        int idx = 0;
+        if (x != x) idx = sd.nknots[k];
+        else
+            for (int j = 0; j < sd.nknots[k]; ++j) idx += (knots[sd.koff[k] + j] <= x) ? 1 : 0;
+        if (idx > sd.shape[k] - 1) idx = sd.shape[k] - 1;
+        flat = flat * sd.shape[k] + idx;
+    }
+    piece[p] = flat;
+    atomicAdd(&counts[flat], 1);
+}
+
+// perm[offset[piece] + slot] = point index (slot order inside a bucket is arbitrary: each
+// point's result does not depend on its neighbours)
+__global__ void k_spline_scatter(const int *__restrict__ piece, long N, int *__restrict__ cursor,
+                                 int *__restrict__ perm) {
+    long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= N) return;
+    int slot = atomicAdd(&cursor[piece[p]], 1);
+    perm[slot] = (int)p;
 }

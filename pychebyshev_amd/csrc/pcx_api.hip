@@ -484,7 +484,9 @@ static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **ou
 // chunk order, which makes every result independent of the batch size.
 template <int KS, int NT>
 static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
-                         double *d_out, long ostride, long ooff, hipStream_t st, bool allow_split) {
+                         double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
+                         const int *perm) {
+    const bool allow_split = split_scratch != nullptr;
     size_t lds = mfma_lds_bytes(h->dims, NT);
     auto kern = k_bary_mfma<KS, NT>;
     if (lds > 64 * 1024)
@@ -502,18 +504,18 @@ static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, cons
     }
     double *partial = nullptr;
     if (nsplit > 1) {
-        int rc = h->s_partial.reserve((size_t)m * nchunks * 4 * (size_t)N * sizeof(double));
+        int rc = split_scratch->reserve((size_t)m * nchunks * 4 * (size_t)N * sizeof(double));
         if (rc) return rc;
-        partial = (double *)h->s_partial.ptr;
+        partial = (double *)split_scratch->ptr;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit, (unsigned)m), dim3(256), lds, st,
                        h->dims, h->plan, h->d_nodes, h->d_wts, frag_tab, h->d_rowcode, h->d_kcode, d_pts,
-                       d_out, N, ostride, ooff, cps, partial);
+                       d_out, N, ostride, ooff, cps, partial, perm);
     HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
         long cnt = N * m;
         hipLaunchKernelGGL(k_bary_reduce, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, partial, d_out,
-                           N, nchunks, m, ostride, ooff);
+                           N, nchunks, m, ostride, ooff, perm);
         HIP_TRY(hipGetLastError());
     }
     return PCX_OK;
@@ -521,9 +523,10 @@ static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, cons
 
 template <int NT>
 static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
-                          double *d_out, long ostride, long ooff, hipStream_t st, bool allow_split) {
+                          double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
+                          const int *perm) {
     switch (h->plan.KS) {
-#define CASE_KS(v) case v: return launch_mfma_t<v, NT>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, allow_split);
+#define CASE_KS(v) case v: return launch_mfma_t<v, NT>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
         CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(6) CASE_KS(8) CASE_KS(12) CASE_KS(16)
         CASE_KS(20) CASE_KS(24) CASE_KS(28) CASE_KS(31) CASE_KS(32)
 #undef CASE_KS
@@ -532,7 +535,7 @@ static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, con
 }
 
 static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
-                       double *d_out, long ostride, long ooff, hipStream_t st) {
+                       double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
     int ppw = 256 / h->lpp;
     size_t lds = (size_t)ppw * h->dims.sum_n * sizeof(double);
     if (lds > 160 * 1024) return fail(PCX_ERR_UNSUPPORTED, "sum of node counts %d too large for the rows kernel", h->dims.sum_n);
@@ -541,16 +544,18 @@ static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts
     long blocks = (N + ppw - 1) / ppw;
     if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
     hipLaunchKernelGGL(k_bary_rows, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->lpp,
-                       h->d_nodes, h->d_wts, dt.plain, d_pts, d_out, N, ostride, ooff);
+                       h->d_nodes, h->d_wts, dt.plain, d_pts, d_out, N, ostride, ooff, perm);
     HIP_TRY(hipGetLastError());
     return PCX_OK;
 }
 
 // Evaluate m specs (dts[0..m)) at N device-resident points; out[p*ostride + ooff + s].
 // frag_tab is a device table holding the m fragment pointers (MFMA path only).
+// split_scratch (nullable): where split launches of small batches keep their per-chunk sums;
+// perm (nullable): evaluate rows perm[0..N) of d_pts / d_out instead of rows 0..N.
 static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const double *const *frag_tab,
                        const double *d_pts, long N, double *d_out, long ostride, long ooff,
-                       hipStream_t st, bool allow_split) {
+                       hipStream_t st, Scratch *split_scratch, const int *perm = nullptr) {
     if (N == 0) return PCX_OK;
     int variant = h->variant;
     if (variant == 0) variant = h->mfma_ok ? 2 : 1;
@@ -558,11 +563,11 @@ static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const doub
         if (!h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
         // two column tiles per wave for throughput; one when the batch cannot fill the chip
         int nt = (N >= 65536) ? h->nt : 1;
-        return nt == 2 ? launch_mfma_nt<2>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, allow_split)
-                       : launch_mfma_nt<1>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, allow_split);
+        return nt == 2 ? launch_mfma_nt<2>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm)
+                       : launch_mfma_nt<1>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
     }
     for (int s = 0; s < m; ++s) {
-        int rc = launch_rows(h, *dts[s], d_pts, N, d_out, ostride, ooff + s, st);
+        int rc = launch_rows(h, *dts[s], d_pts, N, d_out, ostride, ooff + s, st, perm);
         if (rc) return rc;
     }
     return PCX_OK;
@@ -580,7 +585,8 @@ extern "C" int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t
     if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : h->stream;
     // split launches share the handle's scratch: only on the handle's own stream
-    return bary_launch(h, &dt, 1, dt->slot, d_pts, (long)N, d_out, 1, 0, st, st == h->stream);
+    return bary_launch(h, &dt, 1, dt->slot, d_pts, (long)N, d_out, 1, 0, st,
+                       st == h->stream ? &h->s_partial : nullptr);
 }
 
 static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs, int m,
@@ -612,7 +618,7 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         if (rc) return rc;
         double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
         HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        rc = bary_launch(h, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, h->stream, true);
+        rc = bary_launch(h, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, h->stream, &h->s_partial);
         if (rc) return rc;
         HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -666,6 +672,178 @@ extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
 extern "C" int pcx_bary_stream(pcx_bary *h, void **stream) {
     if (!h || !stream) return fail(PCX_ERR_INVALID, "NULL argument");
     *stream = (void *)h->stream;
+    return PCX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// spline (piecewise) handle
+// ---------------------------------------------------------------------------------
+struct pcx_spline {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    SplineDims sd;
+    int n_pieces = 0;
+    std::vector<pcx_bary *> pieces;      // borrowed
+    double *d_knots = nullptr;
+    int *d_counts = nullptr;             // n_pieces: histogram, then bucket cursors
+    std::mutex mu;
+    Scratch s_pts, s_out, s_piece, s_perm, s_partial;
+};
+
+extern "C" int pcx_spline_destroy(pcx_spline *h) {
+    if (!h) return PCX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    (void)hipFree(h->d_knots);
+    (void)hipFree(h->d_counts);
+    h->s_pts.release(); h->s_out.release(); h->s_piece.release(); h->s_perm.release(); h->s_partial.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PCX_OK;
+}
+
+extern "C" int pcx_spline_create(int device, int d, const int32_t *n_knots, const double *knots_cat,
+                                 pcx_bary *const *pieces, int n_pieces, pcx_spline **out) {
+    if (!out) return fail(PCX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (d < 1 || d > PCX_MAX_DIMS || !n_knots || !pieces) return fail(PCX_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    pcx_spline *h = new (std::nothrow) pcx_spline();
+    if (!h) return fail(PCX_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->sd.d = d;
+    long total = 1;
+    int nk_total = 0;
+    for (int k = 0; k < PCX_MAX_DIMS; ++k) { h->sd.nknots[k] = 0; h->sd.koff[k] = 0; h->sd.shape[k] = 1; }
+    for (int k = 0; k < d; ++k) {
+        if (n_knots[k] < 0 || n_knots[k] > 4096) { delete h; return fail(PCX_ERR_INVALID, "n_knots[%d]=%d", k, n_knots[k]); }
+        h->sd.nknots[k] = n_knots[k];
+        h->sd.koff[k] = nk_total;
+        h->sd.shape[k] = n_knots[k] + 1;
+        for (int j = 1; j < n_knots[k]; ++j)
+            if (!(knots_cat[nk_total + j - 1] <= knots_cat[nk_total + j])) { delete h; return fail(PCX_ERR_INVALID, "knots of dimension %d are not sorted", k); }
+        nk_total += n_knots[k];
+        total *= n_knots[k] + 1;
+        if (total > (1 << 20)) { delete h; return fail(PCX_ERR_UNSUPPORTED, "more than 2^20 pieces"); }
+    }
+    if (n_pieces != total) { delete h; return fail(PCX_ERR_INVALID, "n_pieces=%d but the knots define %ld pieces", n_pieces, total); }
+    if (nk_total > 0 && !knots_cat) { delete h; return fail(PCX_ERR_INVALID, "knots_cat is NULL"); }
+    for (int i = 0; i < n_pieces; ++i) {
+        if (!pieces[i] || pieces[i]->device != device || pieces[i]->dims.d != d) { delete h; return fail(PCX_ERR_INVALID, "piece %d is NULL, on another device or of another dimension", i); }
+        h->pieces.push_back(pieces[i]);
+    }
+    h->n_pieces = n_pieces;
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_knots, (nk_total ? nk_total : 1) * sizeof(double));
+    if (e == hipSuccess && nk_total) e = hipMemcpy(h->d_knots, knots_cat, nk_total * sizeof(double), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&h->d_counts, (size_t)n_pieces * sizeof(int));
+    if (e != hipSuccess) { int c = fail(PCX_ERR_HIP, "spline create: %s", hipGetErrorString(e)); pcx_spline_destroy(h); return c; }
+    *out = h;
+    return PCX_OK;
+}
+
+// Route + bucket cnt device-resident points; returns the per-piece counts/offsets on the host
+// and leaves the bucket permutation in h->s_perm.  Caller holds h->mu.
+static int spline_bucket(pcx_spline *h, const double *dp, long cnt, std::vector<int> &counts,
+                         std::vector<int> &offsets) {
+    int rc = h->s_piece.reserve((size_t)cnt * sizeof(int));
+    if (rc) return rc;
+    rc = h->s_perm.reserve((size_t)cnt * sizeof(int));
+    if (rc) return rc;
+    int *piece = (int *)h->s_piece.ptr, *perm = (int *)h->s_perm.ptr;
+    HIP_TRY(hipMemsetAsync(h->d_counts, 0, (size_t)h->n_pieces * sizeof(int), h->stream));
+    unsigned blocks = (unsigned)((cnt + 255) / 256);
+    hipLaunchKernelGGL(k_spline_piece_id, dim3(blocks), dim3(256), 0, h->stream, h->sd, h->d_knots, dp, cnt, piece, h->d_counts);
+    HIP_TRY(hipGetLastError());
+    counts.assign(h->n_pieces, 0);
+    HIP_TRY(hipMemcpyAsync(counts.data(), h->d_counts, (size_t)h->n_pieces * sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    offsets.assign(h->n_pieces, 0);
+    int acc = 0;
+    for (int i = 0; i < h->n_pieces; ++i) { offsets[i] = acc; acc += counts[i]; }
+    HIP_TRY(hipMemcpyAsync(h->d_counts, offsets.data(), (size_t)h->n_pieces * sizeof(int), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_spline_scatter, dim3(blocks), dim3(256), 0, h->stream, piece, cnt, h->d_counts, perm);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(h->stream));   // `offsets` (pageable) must stay valid until copied
+    return PCX_OK;
+}
+
+static int spline_eval_host(pcx_spline *h, const double *pts, int64_t N, const int32_t *derivs, int m,
+                            double *out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (m > kMaxSpecs) return fail(PCX_ERR_UNSUPPORTED, "more than %d derivative specs in one call", kMaxSpecs);
+    if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int d = h->sd.d;
+    for (int64_t start = 0; start < N; start += kChunkPoints) {
+        long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
+        int rc = h->s_pts.reserve((size_t)cnt * d * sizeof(double));
+        if (rc) return rc;
+        rc = h->s_out.reserve((size_t)cnt * m * sizeof(double));
+        if (rc) return rc;
+        double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
+        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        std::vector<int> counts, offsets;
+        rc = spline_bucket(h, dp, cnt, counts, offsets);
+        if (rc) return rc;
+        const int *perm = (const int *)h->s_perm.ptr;
+        for (int i = 0; i < h->n_pieces; ++i) {
+            if (counts[i] == 0) continue;
+            pcx_bary *pc = h->pieces[i];
+            std::lock_guard<std::mutex> plk(pc->mu);
+            std::vector<DerivedTensor *> dts(m);
+            for (int s = 0; s < m; ++s) {
+                rc = bary_get_tensor(pc, derivs ? derivs + (size_t)s * d : nullptr, &dts[s]);
+                if (rc) return rc;
+            }
+            const double *const *frag_tab = dts[0]->slot;
+            if (m > 1 && pc->mfma_ok) {
+                std::vector<double *> tab(m);
+                for (int s = 0; s < m; ++s) tab[s] = dts[s]->frag;
+                HIP_TRY(hipStreamSynchronize(h->stream));   // earlier launches may still read d_tab
+                HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+                frag_tab = pc->d_tab;
+            }
+            rc = bary_launch(pc, dts.data(), m, frag_tab, dp, counts[i], dout, m, 0, h->stream, &h->s_partial,
+                             perm + offsets[i]);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return PCX_OK;
+}
+
+extern "C" int pcx_spline_eval_batch(pcx_spline *h, const double *pts, int64_t N, const int32_t *deriv,
+                                     double *out) {
+    return spline_eval_host(h, pts, N, deriv, 1, out);
+}
+
+extern "C" int pcx_spline_eval_multi_batch(pcx_spline *h, const double *pts, int64_t N,
+                                           const int32_t *derivs, int m, double *out) {
+    if (!derivs) return fail(PCX_ERR_INVALID, "derivs is NULL");
+    return spline_eval_host(h, pts, N, derivs, m, out);
+}
+
+extern "C" int pcx_spline_piece_ids(pcx_spline *h, const double *pts, int64_t N, int32_t *ids_out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0) return fail(PCX_ERR_INVALID, "N < 0");
+    if (N == 0) return PCX_OK;
+    if (!pts || !ids_out) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (N > kChunkPoints) return fail(PCX_ERR_UNSUPPORTED, "more than %lld points", (long long)kChunkPoints);
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int d = h->sd.d;
+    int rc = h->s_pts.reserve((size_t)N * d * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(h->s_pts.ptr, pts, (size_t)N * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    std::vector<int> counts, offsets;
+    rc = spline_bucket(h, (const double *)h->s_pts.ptr, (long)N, counts, offsets);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ids_out, h->s_piece.ptr, (size_t)N * sizeof(int), hipMemcpyDeviceToHost));
     return PCX_OK;
 }
 

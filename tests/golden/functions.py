@@ -91,3 +91,28 @@ def bs5_query_points(n, seed=99):
     import numpy as np
     rng = np.random.default_rng(seed)
     return np.column_stack([rng.uniform(lo, hi, n) for lo, hi in BS5_DOMAIN])
+
+
+# ---- piecewise (spline) cases ----------------------------------------------------
+def abs_1d(x, _=None):
+    return abs(x[0])
+
+
+def kink_2d(x, _=None):
+    """Kinks at x0 = 0.2 and x1 = 0.5."""
+    return abs(x[0] - 0.2) * math.exp(x[1]) + max(x[1] - 0.5, 0.0) ** 2
+
+
+def call_payoff_3d(x, _=None):
+    """Near-expiry call C(S, T, sigma), K = 100: almost a kink at S = K."""
+    return bs_call_price(S=x[0], K=100.0, T=x[1], r=0.05, sigma=x[2], q=BS_Q)
+
+
+SPLINE_CASES = {
+    "a": dict(f="abs_1d", d=1, domain=[[-1.0, 1.0]], n_nodes=[8], knots=[[0.0]],
+              specs=[[0], [1], [2]]),
+    "b": dict(f="kink_2d", d=2, domain=[[-1.0, 1.0], [0.0, 1.0]], n_nodes=[[7, 9], [6, 8]],
+              knots=[[0.2], [0.5]], specs=[[0, 0], [1, 0], [0, 2], [1, 1]]),
+    "c": dict(f="call_payoff_3d", d=3, domain=[[80.0, 120.0], [0.01, 0.25], [0.1, 0.4]], n_nodes=[9, 7, 6],
+              knots=[[95.0, 100.0, 105.0], [], [0.2]], specs=[[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 0, 1]]),
+}

@@ -283,6 +283,44 @@ def main():
         g8[f"{tag}_out"] = np.stack([c.vectorized_eval_batch(pts_, s) for s in specs_])
     save("g8_small_bary", **g8)
 
+    # ---------------------------------------------------------------- g9 (splines, row f2)
+    from pychebyshev import ChebyshevSpline
+    g9 = {}
+    for tag, case in F.SPLINE_CASES.items():
+        fn = getattr(F, case["f"])
+        sp = ChebyshevSpline(fn, case["d"], case["domain"], n_nodes=[list(v) if isinstance(v, list) else v for v in case["n_nodes"]],
+                             knots=case["knots"])
+        sp.build(verbose=False)
+        rngs = np.random.default_rng(900 + ord(tag))
+        pts_ = np.column_stack([rngs.uniform(lo_, hi_, 3000) for lo_, hi_ in case["domain"]])
+        # rows 0..19: a coordinate exactly on a knot (value specs only are defined there)
+        row = 0
+        for dd_, kn in enumerate(case["knots"]):
+            for kv in kn:
+                pts_[row, dd_] = kv
+                pts_[row + 1, dd_] = kv
+                row += 2
+        # rows 20..29: on domain boundaries; rows 30..39: exactly on nodes of their piece
+        for i in range(20, 30):
+            for dd_, (lo_, hi_) in enumerate(case["domain"]):
+                pts_[i, dd_] = lo_ if (i + dd_) % 2 else hi_
+        for i in range(30, 40):
+            _, pc = sp._find_piece(list(pts_[i]))
+            for dd_ in range(case["d"]):
+                pts_[i, dd_] = pc.nodes[dd_][rngs.integers(0, len(pc.nodes[dd_]))]
+        outs_ = []
+        for s_ in case["specs"]:
+            outs_.append(sp.eval_batch(pts_, s_))
+        g9[f"{tag}_points"] = pts_
+        g9[f"{tag}_out"] = np.stack(outs_)
+        g9[f"{tag}_npieces"] = np.array(sp.num_pieces)
+        g9[f"{tag}_evals"] = np.array(sp.total_build_evals)
+        g9[f"{tag}_single"] = np.array([sp.eval(list(pts_[i]), case["specs"][0]) for i in range(40, 48)])
+        g9[f"{tag}_multi"] = np.array([sp.eval_multi(list(pts_[i]), case["specs"]) for i in range(40, 48)])
+        for j_, pc in enumerate(sp._pieces):
+            g9[f"{tag}_piece{j_}"] = pc.tensor_values
+    save("g9_splines", **g9)
+
     print(f"done in {time.time() - t0:.1f}s")
 
 

@@ -130,8 +130,8 @@ def test_constructor_and_unbuilt_errors():
         ChebyshevApproximation(f, 2, [[0, 1], [0, 1]], [3, 3], max_n=2)
     with pytest.raises(ValueError):
         ChebyshevApproximation(f, 2, [[0, 1], [0, 1]], [3, 3], special_points=[[]])
-    with pytest.raises(NotImplementedError):
-        ChebyshevApproximation(f, 1, [[0, 1]], [3], special_points=[[0.5]])
+    sp = ChebyshevApproximation(f, 1, [[0, 1]], [3], special_points=[[0.5]])
+    assert type(sp).__name__ == "ChebyshevSpline" and sp.num_pieces == 2 and sp.knots == [[0.5]]
     c = ChebyshevApproximation(f, 2, Domain([(0, 1), (0, 1)]), Ns([3, 3]), special_points=SpecialPoints([[], []]))
     assert c.n_nodes == [3, 3] and c.domain == [(0, 1), (0, 1)]
     for call in (lambda: c.eval([0.5, 0.5], [0, 0]), lambda: c.vectorized_eval([0.5, 0.5], [0, 0]),
