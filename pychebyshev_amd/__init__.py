@@ -36,8 +36,9 @@ class SpecialPoints:
 
 
 from .barycentric import ChebyshevApproximation  # noqa: E402
+from .slider import ChebyshevSlider  # noqa: E402
 from .spline import ChebyshevSpline  # noqa: E402
 from .tensor_train import ChebyshevTT  # noqa: E402
 
-__all__ = ["ChebyshevApproximation", "ChebyshevSpline", "ChebyshevTT", "Domain", "Ns", "SpecialPoints",
-           "__version__"]
+__all__ = ["ChebyshevApproximation", "ChebyshevSlider", "ChebyshevSpline", "ChebyshevTT", "Domain", "Ns",
+           "SpecialPoints", "__version__"]

@@ -1,0 +1,225 @@
+"""``ChebyshevSlider`` -- additive "sliding" decomposition around a pivot point: a sum of
+low-dimensional barycentric interpolants, each evaluated on an MI355X.
+
+Host-side mirror of the reference class (``/root/reference/src/pychebyshev/slider.py``,
+v0.21.1) for the evaluation path:
+
+    __init__ / build (one ChebyshevApproximation per partition group)   (:80-199)
+    eval / eval_multi   f(x) ~ f(z) + sum_i [ s_i(x_i) - f(z) ]          (:247-341)
+    get_derivative_id, total_build_evals, pickle, repr
+
+``eval_batch`` / ``eval_multi_batch`` are extensions (the reference has no batch method):
+every slide evaluates the whole batch in one device launch and the k slide results are
+added on the host in the reference's order.
+
+Out of scope in this tier: algebra, calculus, extrude/slice, plotting.
+"""
+from __future__ import annotations
+
+import pickle
+import time
+import warnings
+from typing import Callable, List, Sequence, Tuple
+
+import numpy as np
+
+from ._version import __version__
+from .barycentric import ChebyshevApproximation
+
+__all__ = ["ChebyshevSlider"]
+
+
+class ChebyshevSlider:
+    """Sum of low-dimensional slides around ``pivot_point`` (signature: reference slider.py:80-90)."""
+
+    def __init__(self, function: Callable, num_dimensions: int,
+                 domain: Sequence[Tuple[float, float]], n_nodes: Sequence[int],
+                 partition: Sequence[Sequence[int]], pivot_point: Sequence[float],
+                 max_derivative_order: int = 2, additional_data: object = None):
+        from . import Domain, Ns
+        if isinstance(domain, Domain):
+            domain = list(domain.bounds)
+        if isinstance(n_nodes, Ns):
+            n_nodes = list(n_nodes.counts)
+        self.function = function
+        self.num_dimensions = num_dimensions
+        self.domain = domain
+        self.n_nodes = n_nodes
+        self.partition = partition
+        self.pivot_point = list(pivot_point)
+        self.max_derivative_order = max_derivative_order
+        self.descriptor = ""
+        self.additional_data = additional_data
+        covered = sorted(d for group in partition for d in group)
+        if covered != list(range(num_dimensions)):
+            raise ValueError(f"Partition must cover all dimensions 0..{num_dimensions - 1} "
+                             f"exactly once. Got dimensions: {covered}")
+        self._dim_to_slide = {d: i for i, group in enumerate(partition) for d in group}
+        self.slides: List[ChebyshevApproximation] = []
+        self.pivot_value = 0.0
+        self._built = False
+        self._cached_error_estimate = None
+        self._derivative_id_registry: dict = {}
+        self._derivative_id_to_orders: list = []
+
+    # ---------------------------------------------------------------- build
+    def build(self, verbose: bool | int = True) -> None:
+        """Build every slide with the other coordinates frozen at the pivot
+        (reference slider.py:128-199)."""
+        start = time.time()
+        self._cached_error_estimate = None
+        self.pivot_value = self.function(self.pivot_point, self.additional_data)
+        if verbose:
+            print(f"Building {self.num_dimensions}D Chebyshev Slider ({len(self.partition)} slides, "
+                  f"{self.total_build_evals:,} evaluations vs {int(np.prod(self.n_nodes)):,} for full tensor)...")
+        self.slides = []
+        for idx, group in enumerate(self.partition):
+            def restricted(sub_point, data, _group=tuple(group), _pivot=tuple(self.pivot_point)):
+                full = list(_pivot)
+                for local, dim in enumerate(_group):
+                    full[dim] = sub_point[local]
+                return self.function(full, data)
+
+            slide = ChebyshevApproximation(restricted, len(group), [self.domain[d] for d in group],
+                                           [self.n_nodes[d] for d in group],
+                                           max_derivative_order=self.max_derivative_order,
+                                           additional_data=self.additional_data)
+            slide.build(verbose=False)
+            self.slides.append(slide)
+            if verbose:
+                print(f"  Slide {idx + 1}/{len(self.partition)}: dims {group}, "
+                      f"{int(np.prod(slide.n_nodes)):,} evals")
+        if verbose:
+            print(f"Build complete in {time.time() - start:.3f}s")
+        self._built = True
+
+    # ---------------------------------------------------------------- evaluation
+    def _active_slides(self, derivative_order):
+        return {self._dim_to_slide[d] for d, o in enumerate(derivative_order) if o > 0}
+
+    def eval(self, point, derivative_order=None, *, derivative_id=None) -> float:
+        """Reference slider.py:247-318 (Ruiz & Zeron eq. 7.5); a derivative involves only the
+        slide that owns the differentiated dimensions, cross-slide mixed partials are 0."""
+        if not self._built:
+            raise RuntimeError("Call build() before eval().")
+        derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
+        active = self._active_slides(derivative_order)
+        if active:
+            if len(active) > 1:
+                return 0.0
+            idx = active.pop()
+            group = self.partition[idx]
+            return self.slides[idx].vectorized_eval([point[d] for d in group],
+                                                    [derivative_order[d] for d in group])
+        result = self.pivot_value
+        for idx, group in enumerate(self.partition):
+            val = self.slides[idx].vectorized_eval([point[d] for d in group], [0] * len(group))
+            result += val - self.pivot_value
+        return result
+
+    def eval_multi(self, point, derivative_orders) -> List[float]:
+        """Reference slider.py:320-341: one ``eval`` per spec."""
+        return [self.eval(point, spec) for spec in derivative_orders]
+
+    def eval_batch(self, points, derivative_order=None, *, derivative_id=None) -> np.ndarray:
+        """Batched :meth:`eval` (extension): each slide evaluates all N points in one launch."""
+        if not self._built:
+            raise RuntimeError("Call build() before eval_batch().")
+        derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
+        pts = np.asarray(points, dtype=float)
+        if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
+            raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
+        active = self._active_slides(derivative_order)
+        if active:
+            if len(active) > 1:
+                return np.zeros(pts.shape[0])
+            idx = active.pop()
+            group = list(self.partition[idx])
+            return self.slides[idx].vectorized_eval_batch(np.ascontiguousarray(pts[:, group]),
+                                                          [derivative_order[d] for d in group])
+        result = np.full(pts.shape[0], float(self.pivot_value))
+        for idx, group in enumerate(self.partition):
+            group = list(group)
+            val = self.slides[idx].vectorized_eval_batch(np.ascontiguousarray(pts[:, group]), [0] * len(group))
+            result += val - self.pivot_value
+        return result
+
+    def eval_multi_batch(self, points, derivative_orders) -> np.ndarray:
+        """``(N, d)`` points x ``m`` specs -> ``(N, m)`` (extension)."""
+        return np.column_stack([self.eval_batch(points, list(spec)) for spec in derivative_orders])
+
+    # ---------------------------------------------------------------- derivative ids
+    def get_derivative_id(self, derivative_order) -> int:
+        if len(derivative_order) != self.num_dimensions:
+            raise ValueError(f"derivative_order length {len(derivative_order)} does not "
+                             f"match num_dimensions {self.num_dimensions}")
+        for d, o in enumerate(derivative_order):
+            if not isinstance(o, (int, np.integer)):
+                raise ValueError(f"derivative_order[{d}] must be int, got {type(o).__name__}")
+            if o < 0 or o > self.max_derivative_order:
+                raise ValueError(f"derivative_order[{d}]={o} out of range [0, {self.max_derivative_order}]")
+        key = tuple(int(o) for o in derivative_order)
+        if key in self._derivative_id_registry:
+            return self._derivative_id_registry[key]
+        new_id = len(self._derivative_id_to_orders)
+        self._derivative_id_registry[key] = new_id
+        self._derivative_id_to_orders.append(key)
+        return new_id
+
+    def _resolve_derivative_args(self, derivative_order, derivative_id):
+        if derivative_order is not None and derivative_id is not None:
+            raise ValueError("provide exactly one of derivative_order or derivative_id, not both")
+        if derivative_order is None and derivative_id is None:
+            raise ValueError("must provide derivative_order or derivative_id")
+        if derivative_id is not None:
+            if derivative_id < 0 or derivative_id >= len(self._derivative_id_to_orders):
+                raise KeyError(f"unknown derivative_id {derivative_id}; register via get_derivative_id() first")
+            return list(self._derivative_id_to_orders[derivative_id])
+        return derivative_order
+
+    # ---------------------------------------------------------------- misc
+    @property
+    def total_build_evals(self) -> int:
+        return sum(int(np.prod([self.n_nodes[d] for d in group])) for group in self.partition)
+
+    def is_construction_finished(self) -> bool:
+        return self._built
+
+    def get_constructor_type(self) -> str:
+        return type(self).__name__
+
+    def get_used_ns(self) -> list:
+        return list(self.n_nodes)
+
+    def __getstate__(self) -> dict:
+        state = self.__dict__.copy()
+        state["function"] = None
+        state["_pychebyshev_version"] = __version__
+        return state
+
+    def __setstate__(self, state: dict) -> None:
+        saved = state.pop("_pychebyshev_version", None)
+        if saved is not None and saved != __version__:
+            warnings.warn(f"This object was saved with pychebyshev {saved}, but you are loading it "
+                          f"with {__version__}. Evaluation results may differ if internal data "
+                          f"layout changed.", UserWarning, stacklevel=2)
+        self.__dict__.update(state)
+        self.function = None
+
+    def save(self, path) -> None:
+        if not self._built:
+            raise RuntimeError("Cannot save an unbuilt ChebyshevSlider. Call build() first.")
+        with open(path, "wb") as f:
+            pickle.dump(self, f, protocol=pickle.HIGHEST_PROTOCOL)
+
+    @classmethod
+    def load(cls, path) -> "ChebyshevSlider":
+        with open(path, "rb") as f:
+            obj = pickle.load(f)  # noqa: S301 - same trust model as the reference
+        if not isinstance(obj, cls):
+            raise TypeError(f"Expected a {cls.__name__} instance, got {type(obj).__name__}")
+        return obj
+
+    def __repr__(self) -> str:
+        return (f"ChebyshevSlider(dims={self.num_dimensions}, slides={len(self.partition)}, "
+                f"partition={self.partition}, built={self._built})")

@@ -116,3 +116,14 @@ SPLINE_CASES = {
     "c": dict(f="call_payoff_3d", d=3, domain=[[80.0, 120.0], [0.01, 0.25], [0.1, 0.4]], n_nodes=[9, 7, 6],
               knots=[[95.0, 100.0, 105.0], [], [0.2]], specs=[[0, 0, 0], [1, 0, 0], [2, 0, 0], [0, 0, 1]]),
 }
+
+
+# ---- additive (slider) cases ------------------------------------------------------
+SLIDER_CASES = {
+    "a": dict(f="sin_sum_3d", d=3, domain=[[-1.0, 1.0]] * 3, n_nodes=[11, 11, 11],
+              partition=[[0], [1], [2]], pivot=[0.0, 0.0, 0.0],
+              specs=[[0, 0, 0], [1, 0, 0], [0, 0, 2], [1, 1, 0]]),
+    "b": dict(f="bs_5d", d=5, domain=BS5_DOMAIN, n_nodes=[9, 9, 7, 7, 5],
+              partition=[[0, 1], [2], [3, 4]], pivot=[100.0, 100.0, 0.6, 0.25, 0.04],
+              specs=[[0, 0, 0, 0, 0], [1, 0, 0, 0, 0], [1, 1, 0, 0, 0], [0, 0, 0, 1, 1], [1, 0, 1, 0, 0]]),
+}

@@ -321,6 +321,21 @@ def main():
             g9[f"{tag}_piece{j_}"] = pc.tensor_values
     save("g9_splines", **g9)
 
+    # ---------------------------------------------------------------- g10 (sliders, row f4)
+    from pychebyshev import ChebyshevSlider
+    g10 = {}
+    for tag, case in F.SLIDER_CASES.items():
+        sl = ChebyshevSlider(getattr(F, case["f"]), case["d"], case["domain"], case["n_nodes"],
+                             partition=case["partition"], pivot_point=case["pivot"])
+        sl.build(verbose=False)
+        rngs = np.random.default_rng(1000 + ord(tag))
+        pts_ = np.column_stack([rngs.uniform(lo_, hi_, 300) for lo_, hi_ in case["domain"]])
+        g10[f"{tag}_points"] = pts_
+        g10[f"{tag}_pivot_value"] = np.array(sl.pivot_value)
+        g10[f"{tag}_out"] = np.array([[sl.eval(list(p), s_) for p in pts_] for s_ in case["specs"]])
+        g10[f"{tag}_evals"] = np.array(sl.total_build_evals)
+    save("g10_sliders", **g10)
+
     print(f"done in {time.time() - t0:.1f}s")
 
 

@@ -311,3 +311,45 @@ def test_c_abi_argument_errors(bs5d):
     # NULL deriv = value spec
     _lib.check(lib.pcx_bary_eval_batch(m.handle, _lib.p_f64(pts), 4, None, _lib.p_f64(out)), lib)
     assert np.array_equal(out, c.vectorized_eval_batch(pts, [0] * 5))
+
+
+def test_host_batches_larger_than_one_staging_chunk(oracle_mod):
+    """Host-pointer batches are staged in 8,388,608-point chunks: cross the boundary."""
+    g = golden("g1_sincos2d")
+    c = ChebyshevApproximation.from_values(g["tensor"], 2, [[-1, 1], [-1, 1]], [12, 12])
+    N = (1 << 23) + 1234
+    rng = np.random.default_rng(8)
+    pts = rng.uniform(-1, 1, (N, 2))
+    y = c.vectorized_eval_batch(pts, [0, 0])
+    assert y.shape == (N,) and np.isfinite(y).all()
+    om = _oracle_model(oracle_mod, c)
+    probe = np.r_[0:2000, (1 << 23) - 1000:(1 << 23) + 1234]
+    assert_parity(y[probe], oracle_mod.bary_eval_batch(om, pts[probe], [0, 0]), 1e-12, "chunk boundary")
+    m = c.vectorized_eval_multi_batch(pts[(1 << 23) - 50:(1 << 23) + 50], [[0, 0], [1, 0]])
+    assert np.array_equal(m[:, 0], y[(1 << 23) - 50:(1 << 23) + 50])
+
+
+def test_concurrent_host_threads_share_one_handle(bs5d):
+    """Handles are mutex-protected: four Python threads, different specs, same object."""
+    import threading
+    c, g = bs5d
+    pts = F.bs5_query_points(20_000, seed=21)
+    specs = [[0] * 5, [1, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 1, 0, 0, 1]]
+    want = [c.vectorized_eval_batch(pts, s) for s in specs]
+    got = [None] * 4
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(5):
+                got[i] = c.vectorized_eval_batch(pts, specs[i])
+        except Exception as exc:       # pragma: no cover
+            errs.append(exc)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs
+    for a, b in zip(got, want):
+        assert np.array_equal(a, b)
