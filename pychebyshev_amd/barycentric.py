@@ -83,6 +83,33 @@ def compute_differentiation_matrix(nodes: np.ndarray, weights: np.ndarray) -> np
     return D
 
 
+def _normalize_n_workers(n_workers):
+    """``None`` (serial), ``-1`` (all CPUs) or a positive int (reference _parallel.py:19-33)."""
+    if n_workers is None:
+        return None
+    if n_workers == -1:
+        return os.cpu_count() or 1
+    if not isinstance(n_workers, int) or n_workers < 1:
+        raise ValueError(f"n_workers must be None, -1, or a positive int, got {n_workers!r}")
+    return n_workers
+
+
+def _call_point(job):
+    """Worker-side shim: unpack ``(function, additional_data, point)`` and evaluate."""
+    fn, data, point = job
+    return float(fn(point, data))
+
+
+def _evaluate_in_parallel(function, points, additional_data, n_workers) -> np.ndarray:
+    """Fan the grid points out over a process pool (reference _parallel.py:36-64; the
+    reference's only parallelism).  ``function`` must be picklable (module level)."""
+    from concurrent.futures import ProcessPoolExecutor
+    jobs = [(function, additional_data, p) for p in points]
+    chunk = max(1, len(jobs) // (4 * n_workers))
+    with ProcessPoolExecutor(max_workers=n_workers) as pool:
+        return np.fromiter(pool.map(_call_point, jobs, chunksize=chunk), dtype=float, count=len(jobs))
+
+
 def _unwrap_typed(domain, n_nodes, special_points):
     from . import Domain, Ns, SpecialPoints
     if isinstance(domain, Domain):
@@ -173,9 +200,7 @@ class ChebyshevApproximation:
         self.special_points = special_points
         self.descriptor = ""
         self.additional_data = additional_data
-        if n_workers is not None and (not isinstance(n_workers, int) or n_workers == 0 or n_workers < -1):
-            raise ValueError(f"n_workers must be None, -1, or a positive int, got {n_workers!r}")
-        self.n_workers = n_workers
+        self.n_workers = _normalize_n_workers(n_workers)
         self._derivative_id_registry: dict = {}
         self._derivative_id_to_orders: list = []
 
@@ -256,10 +281,14 @@ class ChebyshevApproximation:
             print(f"Building {self.num_dimensions}D Chebyshev approximation ({total:,} evaluations)...")
         start = time.time()
         self._cached_error_estimate = None
-        values = np.zeros(self.n_nodes)
         fn, data, grid = self.function, self.additional_data, self.nodes
-        for idx in np.ndindex(*self.n_nodes):
-            values[idx] = float(fn([grid[d][i] for d, i in enumerate(idx)], data))
+        if self.n_workers is None or self.n_workers == 1:
+            values = np.zeros(self.n_nodes)
+            for idx in np.ndindex(*self.n_nodes):
+                values[idx] = float(fn([grid[d][i] for d, i in enumerate(idx)], data))
+        else:
+            points = [[grid[d][i] for d, i in enumerate(idx)] for idx in np.ndindex(*self.n_nodes)]
+            values = _evaluate_in_parallel(fn, points, data, self.n_workers).reshape(self.n_nodes)
         self.n_evaluations = total
         if not np.isfinite(values).all():
             n_bad = int(np.sum(~np.isfinite(values)))

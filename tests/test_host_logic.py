@@ -103,6 +103,18 @@ def test_build_fills_tensor_in_c_order(capsys):
     assert c.tensor_values[2, 1] == c.nodes[0][2] * 10 + c.nodes[1][1] + 0.5
 
 
+def test_parallel_build_equals_serial_build():
+    serial = ChebyshevApproximation(F.bs_3d, 3, [[50, 150], [0.1, 2.0], [0.1, 0.5]], [7, 6, 5])
+    serial.build(verbose=False)
+    par = ChebyshevApproximation(F.bs_3d, 3, [[50, 150], [0.1, 2.0], [0.1, 0.5]], [7, 6, 5], n_workers=2)
+    par.build(verbose=False)
+    assert par.n_workers == 2 and np.array_equal(par.tensor_values, serial.tensor_values)
+    assert ChebyshevApproximation(F.bs_3d, 3, [[50, 150], [0.1, 2.0], [0.1, 0.5]], [3, 3, 3], n_workers=-1).n_workers >= 1
+    for bad in (0, -2, 1.5):
+        with pytest.raises(ValueError):
+            ChebyshevApproximation(F.bs_3d, 3, [[50, 150], [0.1, 2.0], [0.1, 0.5]], [3, 3, 3], n_workers=bad)
+
+
 def test_from_values_and_nodes_validation():
     with pytest.raises(ValueError):
         ChebyshevApproximation.from_values(np.ones((3, 3)), 2, [[0, 1]], [3, 3])
