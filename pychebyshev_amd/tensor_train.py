@@ -468,6 +468,25 @@ class ChebyshevTT:
         it = iter(vals)
         return run(lambda p: float(next(it)))         # pass 2: same traversal, real values
 
+    def to_dense(self) -> np.ndarray:
+        """Full tensor of values on the Chebyshev grid, axes in the user's dimension order
+        (reference :1874-1917).  One device batch over all ``prod(n_nodes)`` grid points
+        replaces the reference's einsum chain over value cores."""
+        self._check_built()
+        d = self.num_dimensions
+        grids = [np.sort(0.5 * (a + b) + 0.5 * (b - a) * chebpts1(n))
+                 for (a, b), n in zip(self.domain, self.n_nodes)]          # storage frame
+        mesh = np.meshgrid(*grids, indexing="ij")
+        pts_storage = np.column_stack([m.ravel() for m in mesh])
+        vals = self._eval_user_points(self._storage_to_user(pts_storage))
+        dense = vals.reshape(tuple(self.n_nodes))
+        if self._dim_order != list(range(d)):
+            inv = [0] * d
+            for pos, orig in enumerate(self._dim_order):
+                inv[orig] = pos
+            dense = np.transpose(dense, axes=inv)
+        return dense
+
     # finite-difference rules, all in storage frame (reference :2322-2463)
     def _fd_step(self, k: int) -> float:
         a, b = self.domain[k]

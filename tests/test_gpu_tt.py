@@ -92,6 +92,35 @@ def test_both_tt_kernel_forms_agree_with_reference():
     assert t.lib.pcx_tt_set_kernel(t.handle, 2) == _lib.PCX_ERR_UNSUPPORTED     # rank 16 > 12
 
 
+def test_to_dense_reproduces_the_grid_values():
+    """to_dense()[i] == eval(node_i) (reference tensor_train.py:1874-1917), also for a
+    permuted dim_order; feeding it to from_values gives a barycentric twin of the TT."""
+    from pychebyshev_amd import ChebyshevApproximation
+    g = golden("g5b_tt_mixed")
+    dom = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
+    cores = _cores(g, "", 4)
+    tt = ChebyshevTT.from_coeff_cores(cores, dom)
+    dense = tt.to_dense()
+    assert dense.shape == (4, 7, 3, 9)
+    twin = ChebyshevApproximation.from_values(dense, 4, dom, [4, 7, 3, 9])
+    assert_parity(twin.vectorized_eval_batch(g["points"], [0, 0, 0, 0]), g["out"], 1e-11, "TT -> dense -> barycentric")
+    idx = (2, 5, 1, 7)
+    node = [twin.nodes[k][idx[k]] for k in range(4)]
+    assert abs(dense[idx] - tt.eval(node)) <= 1e-13 * np.max(np.abs(dense))
+    perm = [2, 0, 3, 1]
+    ttp = ChebyshevTT.from_coeff_cores(cores, dom, dim_order=perm)
+    densep = ttp.to_dense()
+    assert densep.shape == tuple(np.array([4, 7, 3, 9])[np.argsort(perm)])
+    user_pt = [0.0] * 4
+    for k in range(4):
+        user_pt[perm[k]] = node[k]
+    uidx = [0] * 4
+    for k in range(4):
+        uidx[perm[k]] = idx[k]
+    assert abs(densep[tuple(uidx)] - ttp.eval(user_pt)) <= 1e-13 * np.max(np.abs(dense))
+    assert abs(densep[tuple(uidx)] - dense[idx]) <= 1e-13 * np.max(np.abs(dense))
+
+
 def test_eval_batch_mixed_ranks_and_domains():
     g = golden("g5b_tt_mixed")
     dom = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
