@@ -102,6 +102,12 @@ int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t N, const i
  * the host (prod n_d doubles) -- lets tests check kernel K3 on its own.               */
 int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, double *tensor_out);
 
+/* Contract axis `axis` of a C-order tensor (d dims, n_nodes) with `vec` (n_nodes[axis]
+ * doubles): out has the remaining d-1 dims.  The device half of
+ * ChebyshevApproximation.slice (barycentric.py:2064-2154, _extrude_slice.py:79-92).   */
+int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const double *tensor,
+                             int axis, const double *vec, double *out);
+
 /* Kernel selection and introspection.  variant: 0 = auto, 1 = row-parallel VALU kernel
  * (any shape), 2 = MFMA kernel (v_mfma_f64_16x16x4_f64).  info_out receives
  * {variant used by auto, row tiles, k-steps, lds bytes, points per workgroup, split}.  */

@@ -523,6 +523,78 @@ class ChebyshevApproximation:
         obj._device_index = None
         return obj
 
+    # ---------------------------------------------------------------- slicing
+    def slice(self, params) -> "ChebyshevApproximation":
+        """Fix one or more dimensions at given values (reference barycentric.py:2064-2154):
+        each sliced axis is contracted with its normalised barycentric weight vector -- or a
+        one-hot row when the value is within 1e-14 of a node -- on the device
+        (``pcx_tensor_contract_axis``).  Returns a new, lower-dimensional built interpolant."""
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        if isinstance(params, tuple) and len(params) == 2 and isinstance(params[0], (int, np.integer)):
+            params = [params]
+        params = [tuple(p) for p in params]
+        if len(params) >= self.num_dimensions:
+            raise ValueError(f"Cannot slice all {self.num_dimensions} dimensions (would produce 0D result)")
+        seen = set()
+        for dim_idx, _value in params:
+            if not isinstance(dim_idx, (int, np.integer)):
+                raise TypeError(f"dim_index must be int, got {type(dim_idx).__name__}")
+            if dim_idx < 0 or dim_idx >= self.num_dimensions:
+                raise ValueError(f"dim_index {dim_idx} out of range [0, {self.num_dimensions - 1}]")
+            if dim_idx in seen:
+                raise ValueError(f"Duplicate dim_index {dim_idx}")
+            seen.add(dim_idx)
+        for dim_idx, value in params:
+            lo, hi = self.domain[dim_idx]
+            if value < lo or value > hi:
+                raise ValueError(f"Slice value {value} for dim {dim_idx} is outside domain [{lo}, {hi}]")
+        lib = _lib.load()
+        device = _lib.default_device() if self._device_index is None else self._device_index
+        tensor = _lib.f64(self.tensor_values)
+        nodes, weights, diffs = list(self.nodes), list(self.weights), list(self.diff_matrices)
+        domain, n_nodes = [list(b) for b in self.domain], list(self.n_nodes)
+        for dim_idx, value in sorted(params, key=lambda p: p[0], reverse=True):
+            diff = value - nodes[dim_idx]
+            nearest = int(np.argmin(np.abs(diff)))
+            if abs(diff[nearest]) < 1e-14:
+                vec = np.zeros(n_nodes[dim_idx])
+                vec[nearest] = 1.0
+            else:
+                u = weights[dim_idx] / diff
+                vec = u / np.sum(u)
+            shape = list(tensor.shape)
+            out = np.empty(shape[:dim_idx] + shape[dim_idx + 1:])
+            _lib.check(lib.pcx_tensor_contract_axis(device, tensor.ndim, _lib.p_i32(_lib.i32(shape)),
+                                                    _lib.p_f64(tensor), int(dim_idx), _lib.p_f64(_lib.f64(vec)),
+                                                    _lib.p_f64(out)), lib)
+            tensor = out
+            for lst in (nodes, weights, diffs, domain, n_nodes):
+                del lst[dim_idx]
+        obj = object.__new__(ChebyshevApproximation)
+        obj.function = None
+        obj.num_dimensions = self.num_dimensions - len(params)
+        obj.domain = domain
+        obj.n_nodes = n_nodes
+        obj._original_n_nodes = list(n_nodes)
+        obj.max_derivative_order = self.max_derivative_order
+        obj.error_threshold = None
+        obj.max_n = self.max_n
+        obj.nodes, obj.weights, obj.diff_matrices = nodes, weights, diffs
+        obj.tensor_values = tensor
+        obj.build_time = 0.0
+        obj.n_evaluations = 0
+        obj.special_points = None
+        obj.descriptor = ""
+        obj.additional_data = None
+        obj.n_workers = None
+        obj._cached_error_estimate = None
+        obj._derivative_id_registry = {}
+        obj._derivative_id_to_orders = []
+        obj._device_model = None
+        obj._device_index = self._device_index
+        return obj
+
     # ---------------------------------------------------------------- persistence
     def __getstate__(self) -> dict:
         """Pickle state without the callable and without the device handle

@@ -34,6 +34,23 @@ __global__ void k_mode_product(const double *__restrict__ in, double *__restrict
 }
 
 // ---------------------------------------------------------------------------------
+// Contraction of one tensor axis with a vector: out[o,q] = sum_j in[o,j,q] * vec[j]
+// (ChebyshevApproximation.slice: vec = normalised barycentric weights or a one-hot row,
+// reference _extrude_slice.py:79-92; the same kernel serves quadrature weights).
+// ---------------------------------------------------------------------------------
+__global__ void k_contract_axis(const double *__restrict__ in, double *__restrict__ out,
+                                const double *__restrict__ vec, long outer, int na, long inner) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= outer * inner) return;
+    long q = idx % inner;
+    long o = idx / inner;
+    const double *src = in + (o * na) * inner + q;
+    double s = 0.0;
+    for (int j = 0; j < na; ++j) s = __builtin_fma(src[(long)j * inner], vec[j], s);
+    out[idx] = s;
+}
+
+// ---------------------------------------------------------------------------------
 // A-fragment packing: frag[t][s][l] = T2[16 t + (l & 15)][4 s + (l >> 4)], zero padded,
 // where T2 is the C-order tensor viewed as (M x K).  One coalesced 512-byte read then
 // feeds one v_mfma_f64_16x16x4_f64 (A operand: lane l holds A[l & 15][l >> 4]).

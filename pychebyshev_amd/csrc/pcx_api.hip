@@ -649,6 +649,38 @@ extern "C" int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, dou
     return PCX_OK;
 }
 
+struct DevBufLite {
+    void *p = nullptr;
+    ~DevBufLite() { if (p) (void)hipFree(p); }
+};
+
+extern "C" int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const double *tensor,
+                                        int axis, const double *vec, double *out) {
+    if (d < 2 || d > PCX_MAX_DIMS || !n_nodes || !tensor || !vec || !out) return fail(PCX_ERR_INVALID, "bad argument");
+    if (axis < 0 || axis >= d) return fail(PCX_ERR_INVALID, "axis %d outside [0, %d)", axis, d);
+    long outer = 1, inner = 1;
+    for (int k = 0; k < d; ++k) {
+        if (n_nodes[k] < 1) return fail(PCX_ERR_INVALID, "n_nodes[%d] < 1", k);
+        if (k < axis) outer *= n_nodes[k];
+        if (k > axis) inner *= n_nodes[k];
+    }
+    const int na = n_nodes[axis];
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBufLite din, dvec, dout;
+    HIP_TRY(hipMalloc(&din.p, (size_t)outer * na * inner * sizeof(double)));
+    HIP_TRY(hipMalloc(&dvec.p, (size_t)na * sizeof(double)));
+    HIP_TRY(hipMalloc(&dout.p, (size_t)outer * inner * sizeof(double)));
+    HIP_TRY(hipMemcpy(din.p, tensor, (size_t)outer * na * inner * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dvec.p, vec, (size_t)na * sizeof(double), hipMemcpyHostToDevice));
+    long cnt = outer * inner;
+    hipLaunchKernelGGL(k_contract_axis, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, 0, (const double *)din.p,
+                       (double *)dout.p, (const double *)dvec.p, outer, na, inner);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dout.p, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+
 extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
     if (variant < 0 || variant > 2) return fail(PCX_ERR_INVALID, "variant %d outside [0, 2]", variant);

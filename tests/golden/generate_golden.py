@@ -336,6 +336,19 @@ def main():
         g10[f"{tag}_evals"] = np.array(sl.total_build_evals)
     save("g10_sliders", **g10)
 
+    # ---------------------------------------------------------------- g11 (slice, row f3)
+    g11 = {}
+    node_val = float(bs.nodes[3][4])
+    cases_sl = {"a": [(2, 0.6)], "b": [(0, 101.5), (4, 0.03)], "c": [(3, node_val)], "d": [(1, 90.0), (2, 1.0), (3, 0.2), (4, 0.08)]}
+    for tag, prm in cases_sl.items():
+        sl_ = bs.slice(prm)
+        keep = [k for k in range(5) if k not in [p_[0] for p_ in prm]]
+        ptsl = F.bs5_query_points(200, seed=77)[:, keep]
+        g11[f"{tag}_tensor"] = sl_.tensor_values
+        g11[f"{tag}_points"] = ptsl
+        g11[f"{tag}_out"] = sl_.vectorized_eval_batch(ptsl, [0] * len(keep))
+    save("g11_slice", params_c_value=np.array(node_val), **g11)
+
     print(f"done in {time.time() - t0:.1f}s")
 
 

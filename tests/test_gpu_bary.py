@@ -353,3 +353,38 @@ def test_concurrent_host_threads_share_one_handle(bs5d):
     assert not errs
     for a, b in zip(got, want):
         assert np.array_equal(a, b)
+
+
+def test_slice_matches_reference(bs5d):
+    """ChebyshevApproximation.slice (reference barycentric.py:2064-2154)."""
+    c, _ = bs5d
+    g = golden("g11_slice")
+    node_val = float(g["params_c_value"])
+    cases = {"a": [(2, 0.6)], "b": [(0, 101.5), (4, 0.03)], "c": [(3, node_val)],
+             "d": [(1, 90.0), (2, 1.0), (3, 0.2), (4, 0.08)]}
+    for tag, prm in cases.items():
+        s = c.slice(prm if tag != "a" else prm[0])          # single tuple form accepted too
+        keep = [k for k in range(5) if k not in [p[0] for p in prm]]
+        assert s.num_dimensions == len(keep) and s.n_nodes == [11] * len(keep)
+        assert s.domain == [list(F.BS5_DOMAIN[k]) for k in keep] and s.function is None
+        scale = np.max(np.abs(g[f"{tag}_tensor"]))
+        assert np.max(np.abs(s.tensor_values - g[f"{tag}_tensor"])) <= 1e-13 * scale
+        if tag == "c":      # slicing exactly at a node is an exact take
+            assert np.array_equal(s.tensor_values, np.take(c.tensor_values, 4, axis=3))
+        assert_parity(s.vectorized_eval_batch(g[f"{tag}_points"], [0] * len(keep)), g[f"{tag}_out"], 1e-12, f"slice {tag}")
+    # a slice evaluates like the parent with the coordinate pinned
+    s = c.slice((2, 0.6))
+    p4 = F.bs5_query_points(64, seed=13)
+    p5 = p4.copy()
+    p5[:, 2] = 0.6
+    assert_parity(s.vectorized_eval_batch(np.delete(p4, 2, axis=1), [0] * 4), c.vectorized_eval_batch(p5, [0] * 5), 1e-12, "slice vs parent")
+    with pytest.raises(ValueError, match="outside domain"):
+        c.slice((0, 500.0))
+    with pytest.raises(ValueError, match="Cannot slice all"):
+        c.slice([(k, F.BS5_DOMAIN[k][0]) for k in range(5)])
+    with pytest.raises(ValueError, match="Duplicate"):
+        c.slice([(1, 95.0), (1, 96.0)])
+    with pytest.raises(TypeError):
+        c.slice([(1.0, 95.0)])
+    with pytest.raises(ValueError, match="out of range"):
+        c.slice((7, 1.0))
