@@ -147,6 +147,30 @@ struct Scratch {
 // Host-pointer batches are processed in chunks so the staging buffers stay bounded.
 static const int64_t kChunkPoints = 1 << 23;
 
+// Small host-pointer batches skip the H2D/D2H copies: the points are memcpy'd into a pinned,
+// device-mapped buffer the kernel reads directly over PCIe, and the results land in a second
+// pinned buffer (coherent host memory: visible after the stream sync).  Two API calls fewer
+// per query; this is the single-query latency path.
+static const size_t kPinnedBytes = 64 * 1024;
+struct Pinned {
+    void *in = nullptr, *out = nullptr;
+    bool tried = false;
+    bool ready() {
+        if (!tried) {
+            tried = true;
+            if (hipHostMalloc(&in, kPinnedBytes, hipHostMallocMapped) != hipSuccess) in = nullptr;
+            if (hipHostMalloc(&out, kPinnedBytes, hipHostMallocMapped) != hipSuccess) out = nullptr;
+            (void)hipGetLastError();
+        }
+        return in && out;
+    }
+    void release() {
+        if (in) (void)hipHostFree(in);
+        if (out) (void)hipHostFree(out);
+        in = out = nullptr;
+    }
+};
+
 // ---------------------------------------------------------------------------------
 // barycentric handle
 // ---------------------------------------------------------------------------------
@@ -174,7 +198,9 @@ struct pcx_bary {
     std::map<std::vector<int>, DerivedTensor> cache;
     Scratch s_pts, s_out;
     double **d_tab = nullptr;        // frag table for multi-spec launches (kMaxSpecs entries)
+    std::vector<double *> tab_host;  // what d_tab currently holds
     Scratch s_partial;               // per-chunk totals of split launches
+    Pinned pin;                      // zero-copy staging for small host-pointer batches
 };
 
 static const int kMaxSpecs = 64;
@@ -226,6 +252,7 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     }
     (void)hipFree(h->d_tab);
     h->s_partial.release();
+    h->pin.release();
     (void)hipFree(h->d_nodes); (void)hipFree(h->d_wts); (void)hipFree(h->d_diff);
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
     h->s_pts.release(); h->s_out.release();
@@ -607,8 +634,21 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
     if (m > 1 && h->mfma_ok) {
         std::vector<double *> tab(m);
         for (int s = 0; s < m; ++s) tab[s] = dts[s]->frag;
-        HIP_TRY(hipMemcpy(h->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+        if (tab != h->tab_host) {   // every earlier launch on this handle has been synchronised
+            HIP_TRY(hipMemcpy(h->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+            h->tab_host = tab;
+        }
         frag_tab = h->d_tab;
+    }
+    if (N > 0 && (size_t)N * d * sizeof(double) <= kPinnedBytes && (size_t)N * m * sizeof(double) <= kPinnedBytes &&
+        h->pin.ready()) {
+        memcpy(h->pin.in, pts, (size_t)N * d * sizeof(double));
+        int rc = bary_launch(h, dts.data(), m, frag_tab, (const double *)h->pin.in, (long)N, (double *)h->pin.out, m, 0,
+                             h->stream, &h->s_partial);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(out, h->pin.out, (size_t)N * m * sizeof(double));
+        return PCX_OK;
     }
     for (int64_t start = 0; start < N; start += kChunkPoints) {
         long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
@@ -835,8 +875,11 @@ static int spline_eval_host(pcx_spline *h, const double *pts, int64_t N, const i
             if (m > 1 && pc->mfma_ok) {
                 std::vector<double *> tab(m);
                 for (int s = 0; s < m; ++s) tab[s] = dts[s]->frag;
-                HIP_TRY(hipStreamSynchronize(h->stream));   // earlier launches may still read d_tab
-                HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+                if (tab != pc->tab_host) {
+                    HIP_TRY(hipStreamSynchronize(h->stream));   // earlier launches may still read d_tab
+                    HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+                    pc->tab_host = tab;
+                }
                 frag_tab = pc->d_tab;
             }
             rc = bary_launch(pc, dts.data(), m, frag_tab, dp, counts[i], dout, m, 0, h->stream, &h->s_partial,
@@ -899,6 +942,7 @@ struct pcx_tt {
     int variant = 0;      // 0 auto, 1 direct form, 2 W-first form
     std::mutex mu;
     Scratch s_pts, s_out;
+    Pinned pin;           // zero-copy staging for small host-pointer batches
 };
 
 extern "C" int pcx_tt_destroy(pcx_tt *h) {
@@ -909,6 +953,7 @@ extern "C" int pcx_tt_destroy(pcx_tt *h) {
     (void)hipFree(h->d_last);
     (void)hipFree(h->d_img);
     h->s_pts.release(); h->s_out.release();
+    h->pin.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PCX_OK;
@@ -1082,6 +1127,14 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
     const int d = h->dims.d;
+    if (N > 0 && (size_t)N * d * sizeof(double) <= kPinnedBytes && h->pin.ready()) {
+        memcpy(h->pin.in, pts, (size_t)N * d * sizeof(double));
+        int rc = tt_launch(h, (const double *)h->pin.in, (long)N, (double *)h->pin.out, h->stream);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(out, h->pin.out, (size_t)N * sizeof(double));
+        return PCX_OK;
+    }
     for (int64_t start = 0; start < N; start += kChunkPoints) {
         long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
         int rc = h->s_pts.reserve((size_t)cnt * d * sizeof(double));
