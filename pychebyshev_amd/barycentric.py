@@ -83,6 +83,18 @@ def compute_differentiation_matrix(nodes: np.ndarray, weights: np.ndarray) -> np
     return D
 
 
+def fejer1_weights(n: int) -> np.ndarray:
+    """Fejer-1 quadrature weights at the n type-I Chebyshev nodes, ascending node order:
+    ``sum(w * f(nodes)) ~ integral of f over [-1, 1]`` (Waldvogel 2006; the reference computes the
+    same cosine sum with a DCT-III, _calculus.py:17-48).  O(n^2), n <= a few hundred."""
+    k = np.arange(0, n, 2)
+    moments = 2.0 / (1.0 - k * k)                     # integral of T_k over [-1, 1], k even
+    j = np.arange(n)
+    cosines = np.cos(np.pi * np.outer(2 * j + 1, k) / (2.0 * n))
+    desc = (moments[0] + 2.0 * (cosines[:, 1:] @ moments[1:])) / n
+    return desc[::-1].copy()
+
+
 def _normalize_n_workers(n_workers):
     """``None`` (serial), ``-1`` (all CPUs) or a positive int (reference _parallel.py:19-33)."""
     if n_workers is None:
@@ -523,7 +535,73 @@ class ChebyshevApproximation:
         obj._device_index = None
         return obj
 
-    # ---------------------------------------------------------------- slicing
+    # ---------------------------------------------------------------- slicing / integration
+    def _reduced(self, tensor, nodes, weights, diffs, domain, n_nodes) -> "ChebyshevApproximation":
+        """New built interpolant over the dimensions that are left (shared by slice/integrate)."""
+        obj = object.__new__(ChebyshevApproximation)
+        obj.function = None
+        obj.num_dimensions = len(n_nodes)
+        obj.domain = domain
+        obj.n_nodes = n_nodes
+        obj._original_n_nodes = list(n_nodes)
+        obj.max_derivative_order = self.max_derivative_order
+        obj.error_threshold = None
+        obj.max_n = self.max_n
+        obj.nodes, obj.weights, obj.diff_matrices = nodes, weights, diffs
+        obj.tensor_values = tensor
+        obj.build_time = 0.0
+        obj.n_evaluations = 0
+        obj.special_points = None
+        obj.descriptor = ""
+        obj.additional_data = None
+        obj.n_workers = None
+        obj._cached_error_estimate = None
+        obj._derivative_id_registry = {}
+        obj._derivative_id_to_orders = []
+        obj._device_model = None
+        obj._device_index = self._device_index
+        return obj
+
+    def _contract(self, tensor: np.ndarray, axis: int, vec: np.ndarray) -> np.ndarray:
+        """tensor x_axis vec on the device (``pcx_tensor_contract_axis``)."""
+        lib = _lib.load()
+        device = _lib.default_device() if self._device_index is None else self._device_index
+        shape = list(tensor.shape)
+        out = np.empty(shape[:axis] + shape[axis + 1:])
+        _lib.check(lib.pcx_tensor_contract_axis(device, tensor.ndim, _lib.p_i32(_lib.i32(shape)),
+                                                _lib.p_f64(_lib.f64(tensor)), int(axis),
+                                                _lib.p_f64(_lib.f64(vec)), _lib.p_f64(out)), lib)
+        return out
+
+    def integrate(self, dims=None, bounds=None):
+        """Integrate over ``dims`` (all by default) with Fejer-1 quadrature at the type-I nodes
+        (reference barycentric.py:2160-2275; Waldvogel 2006): each axis is contracted on the
+        device with ``w_j (b - a) / 2``.  Returns a float when no dimension is left, else a
+        lower-dimensional interpolant.  Sub-interval ``bounds`` are not implemented here."""
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        if bounds is not None:
+            raise NotImplementedError("sub-interval integration bounds are outside this build's scope")
+        if dims is None:
+            dims = list(range(self.num_dimensions))
+        elif isinstance(dims, (int, np.integer)):
+            dims = [int(dims)]
+        dims = sorted(set(dims))
+        for d in dims:
+            if d < 0 or d >= self.num_dimensions:
+                raise ValueError(f"dim {d} out of range [0, {self.num_dimensions - 1}]")
+        tensor = _lib.f64(self.tensor_values)
+        nodes, weights, diffs = list(self.nodes), list(self.weights), list(self.diff_matrices)
+        domain, n_nodes = [list(b) for b in self.domain], list(self.n_nodes)
+        for d in sorted(dims, reverse=True):
+            a, b = domain[d]
+            tensor = self._contract(tensor, d, fejer1_weights(n_nodes[d]) * ((b - a) / 2.0))
+            for lst in (nodes, weights, diffs, domain, n_nodes):
+                del lst[d]
+        if not n_nodes:
+            return float(tensor)
+        return self._reduced(tensor, nodes, weights, diffs, domain, n_nodes)
+
     def slice(self, params) -> "ChebyshevApproximation":
         """Fix one or more dimensions at given values (reference barycentric.py:2064-2154):
         each sliced axis is contracted with its normalised barycentric weight vector -- or a
@@ -549,8 +627,6 @@ class ChebyshevApproximation:
             lo, hi = self.domain[dim_idx]
             if value < lo or value > hi:
                 raise ValueError(f"Slice value {value} for dim {dim_idx} is outside domain [{lo}, {hi}]")
-        lib = _lib.load()
-        device = _lib.default_device() if self._device_index is None else self._device_index
         tensor = _lib.f64(self.tensor_values)
         nodes, weights, diffs = list(self.nodes), list(self.weights), list(self.diff_matrices)
         domain, n_nodes = [list(b) for b in self.domain], list(self.n_nodes)
@@ -563,37 +639,10 @@ class ChebyshevApproximation:
             else:
                 u = weights[dim_idx] / diff
                 vec = u / np.sum(u)
-            shape = list(tensor.shape)
-            out = np.empty(shape[:dim_idx] + shape[dim_idx + 1:])
-            _lib.check(lib.pcx_tensor_contract_axis(device, tensor.ndim, _lib.p_i32(_lib.i32(shape)),
-                                                    _lib.p_f64(tensor), int(dim_idx), _lib.p_f64(_lib.f64(vec)),
-                                                    _lib.p_f64(out)), lib)
-            tensor = out
+            tensor = self._contract(tensor, int(dim_idx), vec)
             for lst in (nodes, weights, diffs, domain, n_nodes):
                 del lst[dim_idx]
-        obj = object.__new__(ChebyshevApproximation)
-        obj.function = None
-        obj.num_dimensions = self.num_dimensions - len(params)
-        obj.domain = domain
-        obj.n_nodes = n_nodes
-        obj._original_n_nodes = list(n_nodes)
-        obj.max_derivative_order = self.max_derivative_order
-        obj.error_threshold = None
-        obj.max_n = self.max_n
-        obj.nodes, obj.weights, obj.diff_matrices = nodes, weights, diffs
-        obj.tensor_values = tensor
-        obj.build_time = 0.0
-        obj.n_evaluations = 0
-        obj.special_points = None
-        obj.descriptor = ""
-        obj.additional_data = None
-        obj.n_workers = None
-        obj._cached_error_estimate = None
-        obj._derivative_id_registry = {}
-        obj._derivative_id_to_orders = []
-        obj._device_model = None
-        obj._device_index = self._device_index
-        return obj
+        return self._reduced(tensor, nodes, weights, diffs, domain, n_nodes)
 
     # ---------------------------------------------------------------- persistence
     def __getstate__(self) -> dict:

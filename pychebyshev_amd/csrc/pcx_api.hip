@@ -696,7 +696,7 @@ struct DevBufLite {
 
 extern "C" int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const double *tensor,
                                         int axis, const double *vec, double *out) {
-    if (d < 2 || d > PCX_MAX_DIMS || !n_nodes || !tensor || !vec || !out) return fail(PCX_ERR_INVALID, "bad argument");
+    if (d < 1 || d > PCX_MAX_DIMS || !n_nodes || !tensor || !vec || !out) return fail(PCX_ERR_INVALID, "bad argument");
     if (axis < 0 || axis >= d) return fail(PCX_ERR_INVALID, "axis %d outside [0, %d)", axis, d);
     long outer = 1, inner = 1;
     for (int k = 0; k < d; ++k) {

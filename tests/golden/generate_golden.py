@@ -347,6 +347,17 @@ def main():
         g11[f"{tag}_tensor"] = sl_.tensor_values
         g11[f"{tag}_points"] = ptsl
         g11[f"{tag}_out"] = sl_.vectorized_eval_batch(ptsl, [0] * len(keep))
+    # integrate (full-domain Fejer-1): scalar, and partial integrals evaluated at points
+    from pychebyshev._calculus import _compute_fejer1_weights
+    g11["int_all"] = np.array(bs.integrate())
+    part = bs.integrate(dims=[1, 3])
+    g11["int_13_tensor"] = part.tensor_values
+    ptsi = F.bs5_query_points(200, seed=78)[:, [0, 2, 4]]
+    g11["int_13_points"] = ptsi
+    g11["int_13_out"] = part.vectorized_eval_batch(ptsi, [0, 0, 0])
+    g11["int_one"] = np.array(a2.integrate())
+    for n_ in (2, 5, 11, 12, 33):
+        g11[f"fejer{n_}"] = _compute_fejer1_weights(n_)
     save("g11_slice", params_c_value=np.array(node_val), **g11)
 
     print(f"done in {time.time() - t0:.1f}s")

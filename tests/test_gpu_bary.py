@@ -388,3 +388,26 @@ def test_slice_matches_reference(bs5d):
         c.slice([(1.0, 95.0)])
     with pytest.raises(ValueError, match="out of range"):
         c.slice((7, 1.0))
+
+
+def test_integrate_matches_reference(bs5d):
+    """ChebyshevApproximation.integrate, full-domain Fejer-1 quadrature (reference
+    barycentric.py:2160-2275, _calculus.py:17-48)."""
+    from pychebyshev_amd.barycentric import fejer1_weights
+    c, _ = bs5d
+    g = golden("g11_slice")
+    for n in (2, 5, 11, 12, 33):
+        assert np.max(np.abs(fejer1_weights(n) - g[f"fejer{n}"])) < 1e-15
+        assert abs(fejer1_weights(n).sum() - 2.0) < 1e-14
+    total = c.integrate()
+    assert isinstance(total, float) and abs(total - float(g["int_all"])) <= 1e-12 * abs(float(g["int_all"]))
+    part = c.integrate(dims=[1, 3])
+    assert part.num_dimensions == 3 and part.domain == [list(F.BS5_DOMAIN[k]) for k in (0, 2, 4)]
+    assert np.max(np.abs(part.tensor_values - g["int_13_tensor"])) <= 1e-13 * np.max(np.abs(g["int_13_tensor"]))
+    assert_parity(part.vectorized_eval_batch(g["int_13_points"], [0, 0, 0]), g["int_13_out"], 1e-12, "partial integral")
+    one = c.integrate(dims=2)
+    assert one.num_dimensions == 4
+    with pytest.raises(ValueError):
+        c.integrate(dims=[5])
+    with pytest.raises(NotImplementedError):
+        c.integrate(dims=[0], bounds=(90.0, 100.0))

@@ -200,6 +200,17 @@ def test_cross_step_invariants(oracle_mod):
         assert np.max(np.abs(chat - want_chat)) < 1e-10
     z = tt_mod._cross_step(np.zeros((12, 3)), 3)
     assert z[2] == 1
+    # the largest unfoldings the kernels accept: 64 columns (rank cap of the eval kernels)
+    for (m, c, true_rank, cap) in ((704, 64, 40, 64), (2048, 32, 32, 20)):
+        C = rng.standard_normal((m, true_rank)) @ rng.standard_normal((true_rank, c))
+        chat, piv, rank = tt_mod._cross_step(C, cap)
+        want_chat, want_piv, want_rank = oracle_mod._cross_step(C, cap)
+        assert rank == want_rank == min(true_rank, cap)
+        assert np.array_equal(piv, want_piv[:rank])
+        assert np.max(np.abs(chat[piv] - np.eye(rank))) < 1e-11
+        assert np.max(np.abs(chat - want_chat)) < 1e-8
+    with pytest.raises(NotImplementedError):
+        tt_mod._cross_step(rng.standard_normal((100, 65)), 65)
 
 
 def test_grid_eval_matches_oracle(oracle_mod):
