@@ -123,6 +123,12 @@ class Bary5D(Workload):
         for s in self.specs:
             oracle.bary_eval_batch(om, pts[:sample], s)
         dt = time.perf_counter() - t0
+        # the reference's own algorithm shape (Python loop of NumPy matvecs), one core
+        npn = 3000
+        t0 = time.perf_counter()
+        oracle.bary_eval_batch_numpy(om, pts[:npn], self.specs[0])
+        self.numpy_loop = {"value": npn / (time.perf_counter() - t0), "unit": "point-evals/s", "cores": 1,
+                           "sample": f"first {npn} points, per-point NumPy loop as in the reference"}
         return sample * len(self.specs) / dt, oracle.num_threads(), \
             f"first {sample} of the 10^6 seed-99 points x {len(self.specs)} spec(s), {dt:.1f} s"
 
@@ -362,6 +368,8 @@ def main():
             line["cpu_baseline"] = {"value": rate, "unit": "point-evals/s", "cores": cores,
                                     "kind": "port", "sample": sample,
                                     "host_cpus": os.cpu_count()}
+            if getattr(wl, "numpy_loop", None):
+                line["cpu_baseline"]["numpy_loop"] = wl.numpy_loop
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 

@@ -131,6 +131,39 @@ def bary_eval_batch(model: BaryModel, pts, order=None) -> np.ndarray:
     return out
 
 
+def bary_eval_batch_numpy(model: BaryModel, pts, order=None) -> np.ndarray:
+    """The reference's batch path in its own shape (barycentric.py:992-1047): derivative
+    passes once with ``@ D.T``, then a Python loop over points doing one reshaped NumPy
+    matvec per dimension.  Used as the "NumPy CPU path" baseline and as a second oracle."""
+    d = model.d
+    n = [int(v) for v in model.n]
+    off = np.concatenate([[0], np.cumsum(n)])
+    off2 = np.concatenate([[0], np.cumsum([v * v for v in n])])
+    nodes = [model.nodes_cat[off[k]:off[k + 1]] for k in range(d)]
+    wts = [model.weights_cat[off[k]:off[k + 1]] for k in range(d)]
+    T = model.tensor
+    if order is not None:
+        for k in range(d - 1, -1, -1):
+            Dk = model.diff_cat[off2[k]:off2[k + 1]].reshape(n[k], n[k])
+            for _ in range(int(order[k])):
+                T = np.moveaxis(np.moveaxis(T, k, -1) @ Dk.T, -1, k)
+    pts = _f64(pts)
+    out = np.empty(pts.shape[0])
+    for i in range(pts.shape[0]):
+        cur = T
+        for k in range(d - 1, -1, -1):
+            diff = pts[i, k] - nodes[k]
+            hit = np.where(np.abs(diff) < 1e-14)[0]
+            if len(hit) > 0:
+                cur = cur[..., hit[0]]
+            else:
+                u = wts[k] / diff
+                flat = cur.reshape(-1, cur.shape[-1]) @ u if cur.ndim > 1 else cur @ u
+                cur = (flat.reshape(cur.shape[:-1]) if cur.ndim > 1 else flat) / np.sum(u)
+        out[i] = float(cur)
+    return out
+
+
 def bary_eval_multi(model: BaryModel, point, orders) -> np.ndarray:
     x = _f64(point)
     orders = _i32(orders).reshape(-1, model.d)

@@ -32,6 +32,7 @@ import numpy as np
 from numpy.polynomial.chebyshev import chebpts1
 
 from . import _lib
+from ._derivative_ids import DerivativeIdMixin
 from ._version import __version__
 
 __all__ = [
@@ -163,7 +164,7 @@ class _DeviceModel:
             pass
 
 
-class ChebyshevApproximation:
+class ChebyshevApproximation(DerivativeIdMixin):
     """Multi-dimensional Chebyshev interpolant evaluated on the GPU.
 
     Parameters mirror the reference (barycentric.py:341-355).  ``function(point, data)``
@@ -416,38 +417,6 @@ class ChebyshevApproximation:
 
     def derivative(self, points, derivative_order) -> np.ndarray:
         return self.vectorized_eval_batch(np.atleast_2d(np.asarray(points, dtype=float)), derivative_order)
-
-    # ---------------------------------------------------------------- derivative ids
-    def get_derivative_id(self, derivative_order) -> int:
-        """Reference barycentric.py:1173-1217."""
-        if len(derivative_order) != self.num_dimensions:
-            raise ValueError(f"derivative_order length {len(derivative_order)} does not "
-                             f"match num_dimensions {self.num_dimensions}")
-        for d, o in enumerate(derivative_order):
-            if not isinstance(o, (int, np.integer)):
-                raise ValueError(f"derivative_order[{d}] must be int, got {type(o).__name__}")
-            if o < 0 or o > self.max_derivative_order:
-                raise ValueError(f"derivative_order[{d}]={o} out of range [0, {self.max_derivative_order}]")
-        key = tuple(int(o) for o in derivative_order)
-        found = self._derivative_id_registry.get(key)
-        if found is not None:
-            return found
-        new_id = len(self._derivative_id_to_orders)
-        self._derivative_id_registry[key] = new_id
-        self._derivative_id_to_orders.append(key)
-        return new_id
-
-    def _resolve_derivative_args(self, derivative_order, derivative_id):
-        """Orders xor id (reference barycentric.py:1219-1243)."""
-        if derivative_order is not None and derivative_id is not None:
-            raise ValueError("provide exactly one of derivative_order or derivative_id, not both")
-        if derivative_order is None and derivative_id is None:
-            raise ValueError("must provide derivative_order or derivative_id")
-        if derivative_id is not None:
-            if derivative_id < 0 or derivative_id >= len(self._derivative_id_to_orders):
-                raise KeyError(f"unknown derivative_id {derivative_id}; register via get_derivative_id() first")
-            return list(self._derivative_id_to_orders[derivative_id])
-        return derivative_order
 
     # ---------------------------------------------------------------- small getters
     def is_construction_finished(self) -> bool:

@@ -24,12 +24,13 @@ from typing import Callable, List, Sequence, Tuple
 import numpy as np
 
 from ._version import __version__
+from ._derivative_ids import DerivativeIdMixin
 from .barycentric import ChebyshevApproximation
 
 __all__ = ["ChebyshevSlider"]
 
 
-class ChebyshevSlider:
+class ChebyshevSlider(DerivativeIdMixin):
     """Sum of low-dimensional slides around ``pivot_point`` (signature: reference slider.py:80-90)."""
 
     def __init__(self, function: Callable, num_dimensions: int,
@@ -147,35 +148,6 @@ class ChebyshevSlider:
     def eval_multi_batch(self, points, derivative_orders) -> np.ndarray:
         """``(N, d)`` points x ``m`` specs -> ``(N, m)`` (extension)."""
         return np.column_stack([self.eval_batch(points, list(spec)) for spec in derivative_orders])
-
-    # ---------------------------------------------------------------- derivative ids
-    def get_derivative_id(self, derivative_order) -> int:
-        if len(derivative_order) != self.num_dimensions:
-            raise ValueError(f"derivative_order length {len(derivative_order)} does not "
-                             f"match num_dimensions {self.num_dimensions}")
-        for d, o in enumerate(derivative_order):
-            if not isinstance(o, (int, np.integer)):
-                raise ValueError(f"derivative_order[{d}] must be int, got {type(o).__name__}")
-            if o < 0 or o > self.max_derivative_order:
-                raise ValueError(f"derivative_order[{d}]={o} out of range [0, {self.max_derivative_order}]")
-        key = tuple(int(o) for o in derivative_order)
-        if key in self._derivative_id_registry:
-            return self._derivative_id_registry[key]
-        new_id = len(self._derivative_id_to_orders)
-        self._derivative_id_registry[key] = new_id
-        self._derivative_id_to_orders.append(key)
-        return new_id
-
-    def _resolve_derivative_args(self, derivative_order, derivative_id):
-        if derivative_order is not None and derivative_id is not None:
-            raise ValueError("provide exactly one of derivative_order or derivative_id, not both")
-        if derivative_order is None and derivative_id is None:
-            raise ValueError("must provide derivative_order or derivative_id")
-        if derivative_id is not None:
-            if derivative_id < 0 or derivative_id >= len(self._derivative_id_to_orders):
-                raise KeyError(f"unknown derivative_id {derivative_id}; register via get_derivative_id() first")
-            return list(self._derivative_id_to_orders[derivative_id])
-        return derivative_order
 
     # ---------------------------------------------------------------- misc
     @property

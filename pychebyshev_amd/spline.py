@@ -29,6 +29,7 @@ from typing import Callable, List, Sequence, Tuple
 import numpy as np
 
 from . import _lib
+from ._derivative_ids import DerivativeIdMixin
 from ._version import __version__
 from .barycentric import ChebyshevApproximation
 
@@ -71,7 +72,7 @@ class _DeviceSpline:
             pass
 
 
-class ChebyshevSpline:
+class ChebyshevSpline(DerivativeIdMixin):
     """Piecewise Chebyshev interpolation with user-specified knots (signature: reference
     spline.py:106-123)."""
 
@@ -334,35 +335,6 @@ class ChebyshevSpline:
         ids = np.zeros(pts.shape[0], dtype=np.int32)
         _lib.check(s.lib.pcx_spline_piece_ids(s.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_i32(ids)), s.lib)
         return ids
-
-    # ---------------------------------------------------------------- derivative ids
-    def get_derivative_id(self, derivative_order) -> int:
-        if len(derivative_order) != self.num_dimensions:
-            raise ValueError(f"derivative_order length {len(derivative_order)} does not "
-                             f"match num_dimensions {self.num_dimensions}")
-        for d, o in enumerate(derivative_order):
-            if not isinstance(o, (int, np.integer)):
-                raise ValueError(f"derivative_order[{d}] must be int, got {type(o).__name__}")
-            if o < 0 or o > self.max_derivative_order:
-                raise ValueError(f"derivative_order[{d}]={o} out of range [0, {self.max_derivative_order}]")
-        key = tuple(int(o) for o in derivative_order)
-        if key in self._derivative_id_registry:
-            return self._derivative_id_registry[key]
-        new_id = len(self._derivative_id_to_orders)
-        self._derivative_id_registry[key] = new_id
-        self._derivative_id_to_orders.append(key)
-        return new_id
-
-    def _resolve_derivative_args(self, derivative_order, derivative_id):
-        if derivative_order is not None and derivative_id is not None:
-            raise ValueError("provide exactly one of derivative_order or derivative_id, not both")
-        if derivative_order is None and derivative_id is None:
-            raise ValueError("must provide derivative_order or derivative_id")
-        if derivative_id is not None:
-            if derivative_id < 0 or derivative_id >= len(self._derivative_id_to_orders):
-                raise KeyError(f"unknown derivative_id {derivative_id}; register via get_derivative_id() first")
-            return list(self._derivative_id_to_orders[derivative_id])
-        return derivative_order
 
     # ---------------------------------------------------------------- properties
     @property

@@ -56,6 +56,17 @@ def test_bary_batch_bs5d_value_and_greeks(oracle_mod):
     assert np.array_equal(y0, g["out"][0][4352:4384])
 
 
+def test_numpy_loop_restatement_matches_reference_and_c_oracle(oracle_mod):
+    o, g = oracle_mod, golden("g2_bs5d")
+    m = _model(o, g, 5)
+    idx = np.r_[0:40, 4224:4232, 4352:4360]
+    for s, ref in zip(g["specs"][:4], g["out"][:4]):
+        y = o.bary_eval_batch_numpy(m, g["points"][idx], s)
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(y - ref[idx])) <= 1e-13 * scale           # same NumPy/BLAS calls as the reference
+        assert np.max(np.abs(y - o.bary_eval_batch(m, g["points"][idx], s))) <= 1e-12 * scale
+
+
 def test_bary_multi_and_single_bs5d(oracle_mod):
     o, g = oracle_mod, golden("g2_bs5d")
     m = _model(o, g, 5)
