@@ -275,3 +275,19 @@ def test_additional_data_is_threaded_through_build():
     tt.build(verbose=False, seed=1)
     assert seen and all(s == {"scale": 3.0} for s in seen)
     assert abs(tt.eval([0.25, 0.5]) - 3.0 * 1.25) < 1e-10
+
+
+def test_points_outside_the_domain_extrapolate_like_the_reference_algorithm(oracle_mod):
+    """No bounds check on eval (reference semantics): Chebyshev polynomials at |s| > 1."""
+    g = golden("g4_tt_bs5d")
+    cores = _cores(g, "r8_", 5)
+    tt = ChebyshevTT.from_coeff_cores(cores, F.BS5_DOMAIN)
+    lo = np.array([b[0] for b in F.BS5_DOMAIN])
+    hi = np.array([b[1] for b in F.BS5_DOMAIN])
+    rng = np.random.default_rng(3)
+    pts = lo + (hi - lo) * rng.uniform(-0.1, 1.1, (500, 5))
+    ref = oracle_mod.tt_eval_batch(cores, F.BS5_DOMAIN, pts)
+    for variant in (1, 2):
+        _set_tt_kernel(tt, variant)
+        y = tt.eval_batch(pts)
+        assert np.max(np.abs(y - ref)) <= 1e-11 * np.max(np.abs(ref)), variant
