@@ -205,7 +205,9 @@ struct pcx_bary {
 
 static const int kMaxSpecs = 64;
 
-static const int kKsList[] = {1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 31, 32};
+// every k-step count up to 32 is instantiated: no padding of the folded K axis beyond 4
+static const int kKsList[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22,
+                              23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
 
 static int pick_ks(int K) {
     int need = (K + 3) / 4;
@@ -554,8 +556,10 @@ static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, con
                           const int *perm) {
     switch (h->plan.KS) {
 #define CASE_KS(v) case v: return launch_mfma_t<v, NT>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
-        CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(6) CASE_KS(8) CASE_KS(12) CASE_KS(16)
-        CASE_KS(20) CASE_KS(24) CASE_KS(28) CASE_KS(31) CASE_KS(32)
+        CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8)
+        CASE_KS(9) CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
+        CASE_KS(17) CASE_KS(18) CASE_KS(19) CASE_KS(20) CASE_KS(21) CASE_KS(22) CASE_KS(23) CASE_KS(24)
+        CASE_KS(25) CASE_KS(26) CASE_KS(27) CASE_KS(28) CASE_KS(29) CASE_KS(30) CASE_KS(31) CASE_KS(32)
 #undef CASE_KS
     }
     return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d", h->plan.KS);

@@ -56,18 +56,15 @@ __device__ __forceinline__ void tt_mfma_nodes(const double *__restrict__ fk, int
         for (int f = 0; f < F; ++f) a[f] = fj[f * 64];
     };
     auto node = [&](const double (&a)[F], int j) {
-        double q[NT];
+        double q[NT];                      // (tprev, tcur) = (T_j, T_{j+1}) on entry
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            if (j == 0) q[nt] = 1.0;
-            else if (j == 1) q[nt] = s[nt];
-            else {
-                double tn = __builtin_fma(2.0 * s[nt], tcur[nt], -tprev[nt]);
-                tprev[nt] = tcur[nt];
-                tcur[nt] = tn;
-                q[nt] = tn;
-            }
+            q[nt] = tprev[nt];
+            const double tn = __builtin_fma(2.0 * s[nt], tcur[nt], -tprev[nt]);
+            tprev[nt] = tcur[nt];
+            tcur[nt] = tn;
         }
+        (void)j;
 #pragma unroll
         for (int c = 0; c < RCX; ++c) {
             double bop[NT];
@@ -198,16 +195,16 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
             for (int c = 0; c < RC; ++c) w[c] = 0.0;
             double tp = 1.0, tc = sc;
             for (int j = 0; j < n; ++j) {
-                double q;
-                if (j == 0) q = 1.0;
-                else if (j == 1) q = sc;
-                else { q = __builtin_fma(2.0 * sc, tc, -tp); tp = tc; tc = q; }
+                const double q = tp;                       // T_j; (tp, tc) = (T_j, T_{j+1})
 #pragma unroll
                 for (int c = 0; c < RC; ++c) {
                     int a = 4 * c + g;
                     double gv = (a < rl_last) ? glast[a * n + j] : 0.0;
                     w[c] = __builtin_fma(q, gv, w[c]);
                 }
+                const double tn = __builtin_fma(2.0 * sc, tc, -tp);
+                tp = tc;
+                tc = tn;
             }
             double y = 0.0;
 #pragma unroll
@@ -288,46 +285,52 @@ __global__ void k_tt_pack_wfirst(const double *__restrict__ G, double *__restric
 
 // One dimension of the W-first form with TL (compile-time) row tiles:
 //   acc[nt][t] = sum_s mfma(frag[s][t], B = T_{4s + g}(x))       (branch-free, unrolled)
+// Lane group g needs only every fourth polynomial, T_g, T_{4+g}, T_{8+g}, ...: they obey
+// the stride-4 Chebyshev recurrence T_{m+4} = 2 T_4 T_m - T_{|m-4|}, so after two selects
+// per dimension the k-step loop costs ONE fma and no lane-dependent select.  Polynomials
+// beyond the node count multiply zero-padded core rows, so they need no masking.
 template <int TL, int NT>
-__device__ __forceinline__ void tt_w_gemm(const double *fk, int n, int ks, int g,
+__device__ __forceinline__ void tt_w_gemm(const double *fk, int ks, int g,
                                           const double (&sc)[NT], pcx_d4 (&acc)[NT][TL]) {
-    double tprev[NT], tcur[NT];
+    double uprev[NT], ucur[NT], c4[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-        tprev[nt] = 1.0;
-        tcur[nt] = sc[nt];
-#pragma unroll
-        for (int t = 0; t < TL; ++t) acc[nt][t] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
+        const double x = sc[nt];
+        const double x2 = 2.0 * x;
+        const double t2 = __builtin_fma(x2, x, -1.0);
+        const double t3 = __builtin_fma(x2, t2, -x);
+        const double t4 = __builtin_fma(x2, t3, -t2);
+        const double tg = (g == 0) ? 1.0 : (g == 1) ? x : (g == 2) ? t2 : t3;      // T_g
+        const double tm = (g == 0) ? t4 : (g == 1) ? t3 : (g == 2) ? t2 : x;       // T_{4-g}
+        c4[nt] = 2.0 * t4;
+        uprev[nt] = tg;
+        ucur[nt] = __builtin_fma(c4[nt], tg, -tm);                                  // T_{4+g}
     }
-    for (int s = 0; s < ks; ++s) {
+    {   // k-step 0: B = T_g
         double a[TL];
 #pragma unroll
-        for (int t = 0; t < TL; ++t) a[t] = fk[(size_t)(s * TL + t) * 64];
-        double bop[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) bop[nt] = 0.0;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-            const int j = 4 * s + jj;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                double q;
-                if (j == 0) q = 1.0;
-                else if (j == 1) q = sc[nt];
-                else {
-                    q = __builtin_fma(2.0 * sc[nt], tcur[nt], -tprev[nt]);
-                    tprev[nt] = tcur[nt];
-                    tcur[nt] = q;
-                }
-                if (j >= n) q = 0.0;
-                bop[nt] = (jj == g) ? q : bop[nt];
-            }
-        }
+        for (int t = 0; t < TL; ++t) a[t] = fk[(size_t)t * 64];
 #pragma unroll
         for (int t = 0; t < TL; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], bop[nt], acc[nt][t], 0, 0, 0);
+                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], uprev[nt], (pcx_d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
+    }
+    for (int s = 1; s < ks; ++s) {
+        double a[TL];
+#pragma unroll
+        for (int t = 0; t < TL; ++t) a[t] = fk[(size_t)(s * TL + t) * 64];
+#pragma unroll
+        for (int t = 0; t < TL; ++t)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], ucur[nt], acc[nt][t], 0, 0, 0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const double un = __builtin_fma(c4[nt], ucur[nt], -uprev[nt]);
+            uprev[nt] = ucur[nt];
+            ucur[nt] = un;
+        }
     }
 }
 
@@ -403,7 +406,7 @@ k_tt_eval_wfirst(TTDims dims, TTWPlan plan, const double *__restrict__ img,
             sc[nt] = 2.0 * (x - dims.lo[0]) / (dims.hi[0] - dims.lo[0]) - 1.0;
         }
         pcx_d4 acc[NT][TL0];
-        tt_w_gemm<TL0, NT>(lds + plan.lds_off[0] + lane, dims.n[0], plan.ks[0], g, sc, acc);
+        tt_w_gemm<TL0, NT>(lds + plan.lds_off[0] + lane, plan.ks[0], g, sc, acc);
         fold(acc, std::integral_constant<int, TL0>{});
     }
     for (int k = 1; k < d - 1; ++k) {
@@ -415,7 +418,7 @@ k_tt_eval_wfirst(TTDims dims, TTWPlan plan, const double *__restrict__ img,
             sc[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;
         }
         pcx_d4 acc[NT][TILES];
-        tt_w_gemm<TILES, NT>(lds + plan.lds_off[k] + lane, dims.n[k], plan.ks[k], g, sc, acc);
+        tt_w_gemm<TILES, NT>(lds + plan.lds_off[k] + lane, plan.ks[k], g, sc, acc);
         fold(acc, std::integral_constant<int, TILES>{});
     }
 
@@ -436,16 +439,16 @@ k_tt_eval_wfirst(TTDims dims, TTWPlan plan, const double *__restrict__ img,
             for (int bi = 0; bi < RB; ++bi) w[bi] = 0.0;
             double tp = 1.0, tc = sc;
             for (int j = 0; j < n; ++j) {
-                double q;
-                if (j == 0) q = 1.0;
-                else if (j == 1) q = sc;
-                else { q = __builtin_fma(2.0 * sc, tc, -tp); tp = tc; tc = q; }
+                const double q = tp;                       // T_j; (tp, tc) = (T_j, T_{j+1})
 #pragma unroll
                 for (int bi = 0; bi < RB; ++bi) {
                     int a = 4 * bi + g;
                     double gv = (a < rl) ? gl[a * n + j] : 0.0;
                     w[bi] = __builtin_fma(q, gv, w[bi]);
                 }
+                const double tn = __builtin_fma(2.0 * sc, tc, -tp);
+                tp = tc;
+                tc = tn;
             }
             double y = 0.0;
 #pragma unroll
