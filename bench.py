@@ -204,6 +204,8 @@ def main():
     ap.add_argument("--workload", default="bary5d")
     ap.add_argument("--points", type=int, default=0, help="query points per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="barycentric kernel: 0 auto, 1 rows, 2 MFMA 16x16x4, 3 MFMA 4x4x4_4b")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -238,6 +240,8 @@ def main():
     dev = local_rank
 
     wl = make_workload(args.workload, args.points)
+    if args.variant and hasattr(wl, "m"):
+        _lib.check(wl.m.lib.pcx_bary_set_kernel(wl.m.handle, args.variant), wl.m.lib)
     n = wl.points_per_gpu
     pts = np.ascontiguousarray(wl.points(rank))
     n_out = n * wl.evals_per_point

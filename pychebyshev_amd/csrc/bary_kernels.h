@@ -250,6 +250,174 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     }
 }
 
+// ---------------------------------------------------------------------------------
+// K1+K2 fused, MFMA form built on v_mfma_f64_4x4x4_4b_f64 (large batches).
+//
+// Why: tools/fp64_peak.hip + tools/fp64_mfma4x4.hip measure 66-67 TFLOP/s for back-to-back
+// v_mfma_f64_16x16x4_f64 (it issues every ~74 cycles, not 64) but 76 TFLOP/s (97 % of peak)
+// for the four-block 4x4x4 form, which issues every 16 cycles.  Same arithmetic, same
+// operands: a 16-row tile x 4 k-step is four instructions, one per group of 4 rows.
+//   lane map (probed, tools/mfma4x4_probe.hip): A: lane = 16k + 4b + i, B: lane = 16k + 4b + j,
+//   D: lane = 16i + 4b + j  (b = block).  Blocks = the four 4-point groups of a 16-point
+//   column tile, so B[nt][s] is EXACTLY the B operand of the 16x16x4 kernel (k = l>>4,
+//   point = l&15) and D = row 4rg + (l>>4), point l&15: a lane sees the same rows
+//   {g, g+4, g+8, g+12} in the same order -> bit-identical results to k_bary_mfma.
+//   A must be the same for the four blocks: the row tile is staged in LDS (a straight copy
+//   of frag[t], double-buffered, one barrier per tile) and read with a broadcast
+//   ds_read_b64 (16 distinct addresses per wave-instruction, conflict-free).
+// 512 threads = 8 waves share each staged tile; every wave owns 32 points (NT = 2).
+// dynamic LDS = 8 * (sum_n + 1) * 32 * 8 + 2 * KS * 64 * 8 bytes.
+// ---------------------------------------------------------------------------------
+template <int KS>
+__global__ void __launch_bounds__(512, 2)
+k_bary_mfma4(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
+             const double *__restrict__ wts, const double *const *__restrict__ frag_tab,
+             const unsigned *__restrict__ rowcode, const unsigned *__restrict__ kcode,
+             const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
+             long ooff, const int *__restrict__ perm) {
+    constexpr int NT = 2;
+    constexpr int PW = 32;
+    constexpr int SLAB = KS * 64;                 // doubles per staged row tile
+    constexpr int CPT = (SLAB + 511) / 512;       // doubles each thread copies per tile
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int g = lane >> 4;
+    const int c = lane & 15;
+    double *bw = lds + (size_t)wave * (dims.sum_n + 1) * PW;
+    double *slab = lds + (size_t)8 * (dims.sum_n + 1) * PW;
+    const long base = ((long)blockIdx.x * 8 + wave) * PW;
+    typedef const double __attribute__((address_space(1))) *gptr_t;
+    const gptr_t frag = (gptr_t)frag_tab[blockIdx.z];
+
+    // ---- prologue 1: barycentric weights (lane -> point lane % 32, dims strided by 2)
+    {
+        const int pp = lane & 31;
+        const int ph = lane >> 5;
+        const long pidx = base + pp;
+        const bool valid = pidx < N;
+        const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
+        for (int k = ph; k < dims.d; k += 2) {
+            const double *nd = nodes + dims.off[k];
+            double x = valid ? pts[row * dims.d + k] : nd[0];
+            bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + (size_t)dims.off[k] * PW + pp, PW);
+        }
+        if (ph == 0) bw[(size_t)dims.sum_n * PW + pp] = 1.0;
+    }
+    // first tile -> LDS, second tile -> registers (in flight)
+    double stage[CPT];
+    auto img_index = [](int i) {       // frag index (s, l = 16k + 4rg + ii)  ->  LDS image index
+        const int s_ = i >> 6, l_ = i & 63;
+        const int k_ = l_ >> 4, rg_ = (l_ >> 2) & 3, ii_ = l_ & 3;
+        return s_ * 64 + (rg_ >> 1) * 32 + (k_ * 4 + ii_) * 2 + (rg_ & 1);
+    };
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) {
+        const int i = threadIdx.x + 512 * r;
+        if (i < SLAB) slab[img_index(i)] = frag[i];
+    }
+    if (plan.MT > 1) {
+#pragma unroll
+        for (int r = 0; r < CPT; ++r) {
+            const int i = threadIdx.x + 512 * r;
+            stage[r] = (i < SLAB) ? frag[(size_t)SLAB + i] : 0.0;
+        }
+    }
+    __syncthreads();
+
+    // ---- prologue 2: B operands in registers (same layout as the 16x16x4 kernel)
+    double B[NT][KS];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        unsigned code = kcode[4 * s + g];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bw + 16 * nt + c, PW);
+    }
+
+    double total[NT], cs[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { total[nt] = 0.0; cs[nt] = 0.0; }
+    // LDS image of a tile: img[s][half][k][i][pair] = frag[s][16k + 4(2 half + pair) + i], so the A
+    // operands of the two row groups a lane multiplies together are one aligned 16-byte read
+    const int aoff = ((lane >> 4) * 4 + (lane & 3)) * 2;
+    for (int t = 0; t < plan.MT; ++t) {
+        const double *cur = slab + (size_t)(t & 1) * SLAB;
+        double *nxt = slab + (size_t)((t + 1) & 1) * SLAB;
+        if (t + 1 < plan.MT) {      // park tile t+1 (free since the barrier that ended tile t-1)
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                const int i = threadIdx.x + 512 * r;
+                if (i < SLAB) nxt[img_index(i)] = stage[r];
+            }
+        }
+        if (t + 2 < plan.MT) {      // fetch tile t+2 while tile t is multiplied
+            const gptr_t src = frag + (size_t)(t + 2) * SLAB;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                const int i = threadIdx.x + 512 * r;
+                stage[r] = (i < SLAB) ? src[i] : 0.0;
+            }
+        }
+        // the tile's four row codes of this lane group, fetched before the MFMA chains
+        const unsigned code0 = rowcode[16 * t + g], code1 = rowcode[16 * t + 4 + g];
+        const unsigned code2 = rowcode[16 * t + 8 + g], code3 = rowcode[16 * t + 12 + g];
+        // two row groups at a time: four independent accumulator chains, and the broadcast
+        // LDS reads of the next DEPTH k-steps are in flight while the current one multiplies
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            constexpr int DEPTH = (KS < 6) ? KS : 6;
+            double acc[2][NT];
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[r][nt] = 0.0;
+            typedef double d2_t __attribute__((ext_vector_type(2)));
+            const d2_t *ar = reinterpret_cast<const d2_t *>(cur + aoff + 32 * half);   // 32 pairs per k-step
+            d2_t ring[DEPTH];
+#pragma unroll
+            for (int s = 0; s < DEPTH; ++s) ring[s] = ar[s * 32];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const double a0 = ring[s % DEPTH][0], a1 = ring[s % DEPTH][1];
+                if (s + DEPTH < KS) ring[s % DEPTH] = ar[(s + DEPTH) * 32];
+                // keep the prefetch ahead of the MFMAs: without the fence hipcc sinks every LDS
+                // read to just before its use (one register pair, lgkmcnt(0) per k-step)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    acc[0][nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a0, B[nt][s], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, B[nt][s], acc[1][nt], 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const unsigned codeA = half ? code2 : code0, codeB = half ? code3 : code1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {      // rows g + 8*half, then g + 8*half + 4: ascending
+                cs[nt] = __builtin_fma(acc[0][nt], code_weight(codeA, bw + 16 * nt + c, PW), cs[nt]);
+                cs[nt] = __builtin_fma(acc[1][nt], code_weight(codeB, bw + 16 * nt + c, PW), cs[nt]);
+            }
+        }
+        const bool chunk_end = ((t + 1) % PCX_CHUNK_TILES == 0) || (t + 1 == plan.MT);
+        if (chunk_end) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) { total[nt] += cs[nt]; cs[nt] = 0.0; }
+        }
+        __syncthreads();            // tile t+1 visible; tile t's buffer free
+    }
+
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        double v = total[nt];
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        long pidx = base + 16 * nt + c;
+        if (g == 0 && pidx < N) {
+            long row = perm ? (long)perm[pidx] : pidx;
+            out[row * ostride + ooff + blockIdx.z] = v;
+        }
+    }
+}
+
 // Finishes a split launch with exactly the additions of a non-split one: per lane group g
 // the chunk sums in chunk order, s_g = ((cs_0 + cs_1) + cs_2) + ..., then (s0 + s1) + (s2 + s3).
 // partial layout: [spec][chunk][group][point].

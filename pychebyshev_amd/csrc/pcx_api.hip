@@ -193,7 +193,8 @@ struct pcx_bary {
     int nt = 2;                      // point tiles per wave in the MFMA kernel
     unsigned *d_rowcode = nullptr, *d_kcode = nullptr;
     int lpp = 64;                    // lanes per point in the rows kernel
-    int variant = 0;                 // 0 auto, 1 rows, 2 mfma
+    bool mfma4_ok = false;           // 4x4x4_4b form available (LDS budget)
+    int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
     Scratch s_pts, s_out;
@@ -237,6 +238,10 @@ static bool plan_mfma(const BaryDims &dm, BaryMfmaPlan &best) {
         }
     }
     return found;
+}
+
+static size_t mfma4_lds_bytes(const BaryDims &dm, int ks) {
+    return ((size_t)8 * (dm.sum_n + 1) * 32 + (size_t)2 * ks * 64) * sizeof(double);
 }
 
 static size_t mfma_lds_bytes(const BaryDims &dm, int nt) {
@@ -339,6 +344,7 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->nt = 1;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->mfma_ok = false;
     }
+    h->mfma4_ok = h->mfma_ok && mfma4_lds_bytes(h->dims, h->plan.KS) <= 160 * 1024;
     if (h->mfma_ok) {
         const BaryMfmaPlan &p = h->plan;
         const unsigned ones = (unsigned)sum_n;  // index of the all-ones table row
@@ -550,6 +556,35 @@ static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, cons
     return PCX_OK;
 }
 
+// 4x4x4_4b form: 512-thread workgroups (8 waves x 32 points), row tiles staged through LDS.
+template <int KS>
+static int launch_mfma4_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
+                          double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
+    size_t lds = mfma4_lds_bytes(h->dims, KS);
+    auto kern = k_bary_mfma4<KS>;
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long blocks = (N + 255) / 256;
+    if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, (unsigned)m), dim3(512), lds, st, h->dims, h->plan,
+                       h->d_nodes, h->d_wts, frag_tab, h->d_rowcode, h->d_kcode, d_pts, d_out, N, ostride, ooff, perm);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+static int launch_mfma4(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
+                        double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
+    switch (h->plan.KS) {
+#define CASE_KS(v) case v: return launch_mfma4_t<v>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+        CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8)
+        CASE_KS(9) CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
+        CASE_KS(17) CASE_KS(18) CASE_KS(19) CASE_KS(20) CASE_KS(21) CASE_KS(22) CASE_KS(23) CASE_KS(24)
+        CASE_KS(25) CASE_KS(26) CASE_KS(27) CASE_KS(28) CASE_KS(29) CASE_KS(30) CASE_KS(31) CASE_KS(32)
+#undef CASE_KS
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d", h->plan.KS);
+}
+
 template <int NT>
 static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
                           double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
@@ -590,6 +625,10 @@ static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const doub
     if (N == 0) return PCX_OK;
     int variant = h->variant;
     if (variant == 0) variant = h->mfma_ok ? 2 : 1;
+    if (variant == 3) {
+        if (!h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
+        return launch_mfma4(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+    }
     if (variant == 2) {
         if (!h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
         // two column tiles per wave for throughput; one when the batch cannot fill the chip
@@ -727,8 +766,9 @@ extern "C" int pcx_tensor_contract_axis(int device, int d, const int32_t *n_node
 
 extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
-    if (variant < 0 || variant > 2) return fail(PCX_ERR_INVALID, "variant %d outside [0, 2]", variant);
+    if (variant < 0 || variant > 3) return fail(PCX_ERR_INVALID, "variant %d outside [0, 3]", variant);
     if (variant == 2 && !h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
+    if (variant == 3 && !h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
     std::lock_guard<std::mutex> lk(h->mu);
     h->variant = variant;
     return PCX_OK;

@@ -52,7 +52,7 @@ def test_config1_sincos_2d_built_through_callback():
     assert np.max(np.abs(y - np.sin(pts[:, 0]) * np.cos(pts[:, 1]))) < 5e-12
 
 
-@pytest.mark.parametrize("variant", [2, 1])
+@pytest.mark.parametrize("variant", [2, 1, 3])
 def test_bs5d_value_and_greeks_match_reference(bs5d, variant):
     c, g = bs5d
     _set_kernel(c, variant)
@@ -190,6 +190,22 @@ def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
     if d > 8 or shape == (2, 200):
         assert info[0] == 1, "expected the rows kernel for this shape"
+
+
+def test_both_mfma_forms_are_bit_identical(bs5d):
+    """The 4x4x4_4b form visits the same rows per lane in the same order as the 16x16x4 form."""
+    c, g = bs5d
+    pts = F.bs5_query_points(100_000, seed=17)
+    pts[:64] = g["points"][4352:4416]                  # exact-node and mixed rows
+    out = {}
+    for variant in (2, 3):
+        _set_kernel(c, variant)
+        out[variant] = (c.vectorized_eval_batch(pts, [0] * 5), c.vectorized_eval_batch(pts, [1, 0, 0, 1, 0]),
+                        c.vectorized_eval_multi_batch(pts[:1000], g["specs"].tolist()),
+                        c.vectorized_eval_batch(pts[:777], [0] * 5))
+    _set_kernel(c, 0)
+    for a, b in zip(out[2], out[3]):
+        assert np.array_equal(a, b)
 
 
 def test_edge_inputs(bs5d):
