@@ -109,7 +109,9 @@ int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const do
                              int axis, const double *vec, double *out);
 
 /* Kernel selection and introspection.  variant: 0 = auto, 1 = row-parallel VALU kernel
- * (any shape), 2 = MFMA kernel (v_mfma_f64_16x16x4_f64).  info_out receives
+ * (any shape), 2 = MFMA kernel (v_mfma_f64_16x16x4_f64), 3 = the same contraction on
+ * v_mfma_f64_4x4x4_4b_f64 with LDS-staged tiles (bit-identical to 2; opt-in, never picked
+ * by auto; PCX_ERR_UNSUPPORTED when the shape is not covered).  info_out receives
  * {variant used by auto, row tiles, k-steps, lds bytes, points per workgroup, split}.  */
 int pcx_bary_set_kernel(pcx_bary *h, int variant);
 int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
