@@ -142,7 +142,7 @@ class TTWork(Workload):
             self.domain = F.BS5_DOMAIN
             self.name = "5D Black-Scholes ChebyshevTT ranks [1,8,8,8,6,1] eval_batch"
             self.flop_per_eval, self.bytes_per_eval = 4560.0, 48.0
-            self.kernel = "k_tt_eval_mfma<2,1,4>"
+            self.kernel = "k_tt_eval_wfirst<8,3,1>"
         else:
             rng = np.random.default_rng(16)
             ranks = [1] + [16] * 9 + [1]

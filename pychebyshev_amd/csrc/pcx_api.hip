@@ -982,6 +982,7 @@ struct pcx_tt {
     // small-rank "W first" form (ranks <= 12, packed cores resident in LDS)
     int wR = 0;           // 0 = not available, else padded rank 4 / 8 / 12
     TTWPlan wplan;
+    long w_resident = 0;  // workgroups of the W-first kernel the device keeps resident (lazy)
     double *d_img = nullptr;
     int variant = 0;      // 0 auto, 1 direct form, 2 W-first form
     std::mutex mu;
@@ -1072,20 +1073,22 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
                            d_cores + coff[k], h->d_frag + h->dims.frag_off[k], ranks[k], n_nodes[k],
                            ranks[k + 1], h->rk.rc[k], h->rk.rt[k]);
     }
-    // W-first image (small ranks): every dim but the last as (R*R) x n GEMM fragments, the
-    // last dim as a plain [a][j] table; the whole image must fit the kernel's LDS budget.
-    if (h->rmax <= 12) {
+    // W-first image (small ranks, n <= 32): every dim but the last as (R*R) x n GEMM fragments
+    // padded to a common k-step count, the last dim as an [R][4 ks] table; the whole image
+    // must fit the kernel's LDS budget.
+    int nmax = 1;
+    for (int k = 0; k < d; ++k) nmax = std::max(nmax, (int)n_nodes[k]);
+    if (h->rmax <= 12 && nmax <= 32) {
         int R = 4 * ((h->rmax + 3) / 4);
+        const int ks = (nmax + 3) / 4;
         long total = 0;
         for (int k = 0; k < d; ++k) {
-            h->wplan.ks[k] = (n_nodes[k] + 3) / 4;
             h->wplan.ntiles[k] = (k == 0) ? (R + 15) / 16 : R * R / 16;   // compile-time tile counts of the kernel
             h->wplan.lds_off[k] = (int)total;
-            total += (k == d - 1) ? (long)ranks[k] * n_nodes[k]
-                                  : (long)h->wplan.ks[k] * h->wplan.ntiles[k] * 64;
+            total += (k == d - 1) ? (long)R * 4 * ks : (long)ks * h->wplan.ntiles[k] * 64;
         }
-        for (int k = d; k < PCX_MAX_DIMS; ++k) { h->wplan.ks[k] = 0; h->wplan.ntiles[k] = 0; h->wplan.lds_off[k] = 0; }
-        h->wplan.rl_last = ranks[d - 1];
+        for (int k = d; k < PCX_MAX_DIMS; ++k) { h->wplan.ntiles[k] = 0; h->wplan.lds_off[k] = 0; }
+        h->wplan.ks = ks;
         h->wplan.total = (int)total;
         if (total * (long)sizeof(double) <= 96 * 1024) {
             h->wR = R;
@@ -1093,13 +1096,13 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
         }
         for (int k = 0; k < d && h->wR; ++k) {
             int last = (k == d - 1);
-            long cnt = last ? (long)ranks[k] * n_nodes[k] : (long)h->wplan.ks[k] * h->wplan.ntiles[k] * 64;
+            long cnt = last ? (long)R * 4 * ks : (long)ks * h->wplan.ntiles[k] * 64;
             dim3 grid((unsigned)((cnt + 255) / 256)), block(256);
             double *dst = h->d_img + h->wplan.lds_off[k];
             const double *src = d_cores + coff[k];
-            if (R == 4) hipLaunchKernelGGL(k_tt_pack_wfirst<4>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], h->wplan.ks[k], h->wplan.ntiles[k], last);
-            else if (R == 8) hipLaunchKernelGGL(k_tt_pack_wfirst<8>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], h->wplan.ks[k], h->wplan.ntiles[k], last);
-            else hipLaunchKernelGGL(k_tt_pack_wfirst<12>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], h->wplan.ks[k], h->wplan.ntiles[k], last);
+            if (R == 4) hipLaunchKernelGGL(k_tt_pack_wfirst<4>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], ks, h->wplan.ntiles[k], last);
+            else if (R == 8) hipLaunchKernelGGL(k_tt_pack_wfirst<8>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], ks, h->wplan.ntiles[k], last);
+            else hipLaunchKernelGGL(k_tt_pack_wfirst<12>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], ks, h->wplan.ntiles[k], last);
         }
     }
     hipError_t e1 = hipGetLastError();
@@ -1112,29 +1115,51 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
     return PCX_OK;
 }
 
-template <int R, int NT>
+template <int R, int KS, int NT>
 static int tt_launch_wfirst(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
-    auto kern = k_tt_eval_wfirst<R, NT>;
-    size_t lds = ((size_t)h->wplan.total + (size_t)4 * 16 * NT * h->dims.d) * sizeof(double);
-    if (lds > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    auto kern = k_tt_eval_wfirst<R, KS, NT>;
+    size_t lds = ((size_t)h->wplan.total + (size_t)(4 + 2) * 16 * NT * h->dims.d) * sizeof(double);
+    if (h->w_resident == 0) {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+        h->w_resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+    }
     long per_wg = 4L * 16 * NT;
     long batches = (N + per_wg - 1) / per_wg;
-    // persistent workgroups: enough to fill every CU a few times over, each walks a
+    // persistent workgroups: exactly as many as the chip keeps resident, each walks a
     // grid-stride range of batches so the LDS image is loaded once per workgroup
-    long blocks = std::min<long>(batches, 256L * 8);
+    long blocks = std::min<long>(batches, h->w_resident);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->wplan, h->d_img, d_pts, d_out, N);
     HIP_TRY(hipGetLastError());
     return PCX_OK;
+}
+
+template <int R, int NT>
+static int tt_launch_wfirst_ks(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
+    switch (h->wplan.ks) {
+    case 1: return tt_launch_wfirst<R, 1, NT>(h, d_pts, N, d_out, st);
+    case 2: return tt_launch_wfirst<R, 2, NT>(h, d_pts, N, d_out, st);
+    case 3: return tt_launch_wfirst<R, 3, NT>(h, d_pts, N, d_out, st);
+    case 4: return tt_launch_wfirst<R, 4, NT>(h, d_pts, N, d_out, st);
+    case 5: return tt_launch_wfirst<R, 5, NT>(h, d_pts, N, d_out, st);
+    case 6: return tt_launch_wfirst<R, 6, NT>(h, d_pts, N, d_out, st);
+    case 7: return tt_launch_wfirst<R, 7, NT>(h, d_pts, N, d_out, st);
+    case 8: return tt_launch_wfirst<R, 8, NT>(h, d_pts, N, d_out, st);
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel: %d k-steps not instantiated", h->wplan.ks);
 }
 
 static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
     if (N == 0) return PCX_OK;
     if (h->variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
     if (h->wR && h->variant != 1) {
-        if (h->wR == 4) return tt_launch_wfirst<4, 4>(h, d_pts, N, d_out, st);
-        if (h->wR == 8) return tt_launch_wfirst<8, 1>(h, d_pts, N, d_out, st);
-        return tt_launch_wfirst<12, 1>(h, d_pts, N, d_out, st);
+        if (h->wR == 4) return tt_launch_wfirst_ks<4, 4>(h, d_pts, N, d_out, st);
+        if (h->wR == 8) return tt_launch_wfirst_ks<8, 1>(h, d_pts, N, d_out, st);
+        return tt_launch_wfirst_ks<12, 1>(h, d_pts, N, d_out, st);
     }
     auto go = [&](auto kern, int nt) -> int {
         long per_wg = 4L * 16 * nt;

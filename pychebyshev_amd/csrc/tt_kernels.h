@@ -110,7 +110,7 @@ struct TTRanks {
 // dimensions in registers.  The last dimension (right rank 1) is a VALU dot product against
 // the plain core `glast` ([a][j]) split over the four lane groups.
 template <int RC, int RT, int NT>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 2)
 k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
                const double *__restrict__ glast, int rl_last,
                const double *__restrict__ pts, double *__restrict__ out, long N) {
@@ -253,23 +253,26 @@ __global__ void k_tt_grid_eval(int d, const int *__restrict__ n, const int *__re
 //   products need only compile-time register indices, and one shuffle per b re-assembles
 //   v' in every lane.  All packed cores live in LDS for the whole kernel.
 // The last dimension (r' = 1) is a VALU dot product split over the four lane groups.
+// Every dimension is zero-padded to the kernel's compile-time KS k-steps, so the whole
+// batch body is straight-line code.
 // =====================================================================================
 struct TTWPlan {
-    int ks[PCX_MAX_DIMS];       // k-steps of 4 covering n_k
     int ntiles[PCX_MAX_DIMS];   // row tiles stored: ceil(R/16) for dim 0 (left rank 1), R*R/16 after
     int lds_off[PCX_MAX_DIMS];  // offset (doubles) of dim k's block inside the LDS image
-    int rl_last;                // left rank of the last dimension
+    int ks;                     // k-steps of 4 every dimension is padded to (= the kernel's KS)
     int total;                  // doubles in the LDS image
 };
 
 // image layout: for k < d-1: frag[k][s][t][64] = G_k[a][4s + (l>>4)][b], m = 16t + (l&15),
-// a = m / R, b = m % R (zero outside the core); last dim: plain [a][j] (rank 1 on the right).
+// a = m / R, b = m % R (zero outside the core); last dim: table [a < R][j < 4 ks], zero padded.
 template <int R>
 __global__ void k_tt_pack_wfirst(const double *__restrict__ G, double *__restrict__ img, int rl,
                                  int n, int rr, int ks, int ntiles, int is_last) {
     long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (is_last) {
-        if (idx < (long)rl * n) img[idx] = G[idx];   // (rl, n, 1) is already [a][j]
+        if (idx >= (long)R * 4 * ks) return;
+        int a = (int)(idx / (4 * ks)), j = (int)(idx % (4 * ks));
+        img[idx] = (a < rl && j < n) ? G[(long)a * n + j] : 0.0;   // (rl, n, 1) is [a][j]
         return;
     }
     long total = (long)ks * ntiles * 64;
@@ -283,16 +286,21 @@ __global__ void k_tt_pack_wfirst(const double *__restrict__ G, double *__restric
     img[idx] = (a < rl && b < rr && j < n) ? G[((long)a * n + j) * rr + b] : 0.0;
 }
 
-// One dimension of the W-first form with TL (compile-time) row tiles:
-//   acc[nt][t] = sum_s mfma(frag[s][t], B = T_{4s + g}(x))       (branch-free, unrolled)
+// One dimension of the W-first form with TL row tiles and KS k-steps (both compile-time):
+//   acc[nt][t] = sum_s mfma(frag[s][t], B = T_{4s + g}(x))
 // Lane group g needs only every fourth polynomial, T_g, T_{4+g}, T_{8+g}, ...: they obey
 // the stride-4 Chebyshev recurrence T_{m+4} = 2 T_4 T_m - T_{|m-4|}, so after two selects
-// per dimension the k-step loop costs ONE fma and no lane-dependent select.  Polynomials
-// beyond the node count multiply zero-padded core rows, so they need no masking.
-template <int TL, int NT>
-__device__ __forceinline__ void tt_w_gemm(const double *fk, int ks, int g,
-                                          const double (&sc)[NT], pcx_d4 (&acc)[NT][TL]) {
-    double uprev[NT], ucur[NT], c4[NT];
+// per dimension a k-step costs ONE fma and no lane-dependent select.  Polynomials beyond
+// the node count multiply zero-padded core rows, so they need no masking.
+template <int TL, int KS, int NT>
+__device__ __forceinline__ void tt_w_gemm(const double *fk, int g, const double (&sc)[NT],
+                                          pcx_d4 (&acc)[NT][TL]) {
+    double a[KS][TL];
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < TL; ++t) a[s][t] = fk[(size_t)(s * TL + t) * 64];
+    double u[NT][KS];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const double x = sc[nt];
@@ -302,65 +310,82 @@ __device__ __forceinline__ void tt_w_gemm(const double *fk, int ks, int g,
         const double t4 = __builtin_fma(x2, t3, -t2);
         const double tg = (g == 0) ? 1.0 : (g == 1) ? x : (g == 2) ? t2 : t3;      // T_g
         const double tm = (g == 0) ? t4 : (g == 1) ? t3 : (g == 2) ? t2 : x;       // T_{4-g}
-        c4[nt] = 2.0 * t4;
-        uprev[nt] = tg;
-        ucur[nt] = __builtin_fma(c4[nt], tg, -tm);                                  // T_{4+g}
-    }
-    {   // k-step 0: B = T_g
-        double a[TL];
+        const double c4 = 2.0 * t4;
+        u[nt][0] = tg;
+        if (KS > 1) u[nt][1] = __builtin_fma(c4, tg, -tm);                          // T_{4+g}
 #pragma unroll
-        for (int t = 0; t < TL; ++t) a[t] = fk[(size_t)t * 64];
+        for (int s = 2; s < KS; ++s) u[nt][s] = __builtin_fma(c4, u[nt][s - 1], -u[nt][s - 2]);
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
         for (int t = 0; t < TL; ++t)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], uprev[nt], (pcx_d4){0.0, 0.0, 0.0, 0.0}, 0, 0, 0);
-    }
-    for (int s = 1; s < ks; ++s) {
-        double a[TL];
-#pragma unroll
-        for (int t = 0; t < TL; ++t) a[t] = fk[(size_t)(s * TL + t) * 64];
-#pragma unroll
-        for (int t = 0; t < TL; ++t)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], ucur[nt], acc[nt][t], 0, 0, 0);
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const double un = __builtin_fma(c4[nt], ucur[nt], -uprev[nt]);
-            uprev[nt] = ucur[nt];
-            ucur[nt] = un;
-        }
-    }
+                acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(
+                    a[s][t], u[nt][s], s == 0 ? (pcx_d4){0.0, 0.0, 0.0, 0.0} : acc[nt][t], 0, 0, 0);
 }
 
-template <int R, int NT>
-__global__ void __launch_bounds__(256)
+// Persistent workgroups of 4 waves; a wave owns 16*NT points per batch.  The query rows of
+// the NEXT batch are fetched (coalesced) while the current one is computed, and are
+// affinely mapped to [-1, 1] -- the reference's 2 (x - a) / (b - a) - 1 with its IEEE
+// division -- on their way into the wave's LDS slice, one element per lane instead of one
+// division per lane and dimension.  __launch_bounds__(256, 2): at most 256 registers per
+// lane, which lets the compiler keep the MFMA accumulators in ordinary VGPRs (no
+// v_accvgpr_read traffic in front of the VALU fold).
+template <int R, int KS, int NT>
+__global__ void __launch_bounds__(256, 2)
 k_tt_eval_wfirst(TTDims dims, TTWPlan plan, const double *__restrict__ img,
                  const double *__restrict__ pts, double *__restrict__ out, long N) {
     constexpr int TILES = R * R / 16 > 0 ? R * R / 16 : 1;
     constexpr int RB = R / 4;                       // outputs b owned per lane group
+    constexpr int PF = 4 * NT;                      // staged elements per lane: 16 NT d / 64, d <= 16
+    constexpr int NP = 4 * KS;                      // padded node count
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int c16 = lane & 15;
     const int d = dims.d;
+    const int cnt = 16 * NT * d;                    // doubles in a wave's block of query rows
     // the packed cores are loaded ONCE per workgroup; the workgroup then walks over many
     // batches of 4 x 16*NT points (grid-stride), so this prologue is amortised
     for (int i = threadIdx.x; i < plan.total; i += 256) lds[i] = img[i];
-    __syncthreads();
-    double *xs = lds + plan.total + (size_t)wave * (16 * NT) * d;
+    // element i of a wave's block is column i % d: table of its storage dimension's bounds
+    double *lo_t = lds + plan.total, *wd_t = lo_t + cnt;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int c = i % d;
+        double lo = 0.0, wd = 1.0;
+        for (int kk = 0; kk < d; ++kk)
+            if (dims.col[kk] == c) { lo = dims.lo[kk]; wd = dims.hi[kk] - dims.lo[kk]; }
+        lo_t[i] = lo;
+        wd_t[i] = wd;
+    }
+    double *xs = wd_t + cnt + (size_t)wave * cnt;
     const long nbatch = (N + 4 * 16 * NT - 1) / (4 * 16 * NT);
-  for (long batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
-    const long base = (batch * 4 + wave) * (16 * NT);
-    {   // the wave's query rows: one contiguous, coalesced block copy into its own LDS slice
-        // (wave-private: LDS operations of one wave execute in order, no barrier needed)
+    double pf[PF];
+    auto fetch = [&](long batch) {
+        const long base = (batch * 4 + wave) * (16 * NT);
         const long first = base * d;
         const long avail = (N - base) * (long)d;
-        const int cnt = 16 * NT * d;
-        for (int i = lane; i < cnt; i += 64) xs[i] = (i < avail) ? pts[first + i] : 0.0;
+#pragma unroll
+        for (int r = 0; r < PF; ++r) {
+            const int i = lane + 64 * r;
+            pf[r] = (i < cnt && i < avail) ? pts[first + i] : 0.0;
+        }
+    };
+    if ((long)blockIdx.x < nbatch) fetch(blockIdx.x);
+    __syncthreads();
+
+  for (long batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+    const long base = (batch * 4 + wave) * (16 * NT);
+    // wave-private LDS slice: LDS operations of one wave execute in order, no barrier needed
+#pragma unroll
+    for (int r = 0; r < PF; ++r) {
+        const int i = lane + 64 * r;
+        if (i < cnt) xs[i] = 2.0 * (pf[r] - lo_t[i]) / wd_t[i] - 1.0;       // tensor_train.py:2254
     }
+    if (batch + gridDim.x < nbatch) fetch(batch + gridDim.x);
 
     double v[NT][R];       // full left vector, replicated in the four lane groups
     double vown[NT][RB];   // the entries a = 4 bi + g this lane group owns
@@ -373,79 +398,68 @@ k_tt_eval_wfirst(TTDims dims, TTWPlan plan, const double *__restrict__ img,
         v[nt][0] = 1.0;
         vown[nt][0] = (g == 0) ? 1.0 : 0.0;
     }
+    // one shuffle per b re-assembles v' in every lane from the owners' partial vectors
+    auto spread = [&](int nt) {
+#pragma unroll
+        for (int b = 0; b < R; ++b) v[nt][b] = __shfl(vown[nt][b >> 2], ((b & 3) << 4) | c16, 64);
+    };
 
-    // fold W into v: v'[b] = sum_a v[a] W[(a,b)] for the b this lane group owns, then one
-    // shuffle per b re-assembles v' in every lane
-    auto fold = [&](auto &acc, auto tl_tag) {
-        constexpr int TL = decltype(tl_tag)::value;
+    if (d > 1) {   // dimension 0 (left rank 1): rows a = 0 only -> v'[b] = W[(0, b)]
+        constexpr int TL0 = (R + 15) / 16;
+        static_assert(TL0 == 1, "R <= 16");
+        double sc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sc[nt] = xs[(16 * nt + c16) * d + dims.col[0]];
+        pcx_d4 acc[NT][TL0];
+        tt_w_gemm<TL0, KS, NT>(lds + plan.lds_off[0] + lane, g, sc, acc);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+            for (int bi = 0; bi < RB; ++bi) vown[nt][bi] = acc[nt][0][bi];
+            spread(nt);
+        }
+    }
+    for (int k = 1; k < d - 1; ++k) {
+        double sc[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sc[nt] = xs[(16 * nt + c16) * d + dims.col[k]];
+        pcx_d4 acc[NT][TILES];
+        tt_w_gemm<TILES, KS, NT>(lds + plan.lds_off[k] + lane, g, sc, acc);
+        // fold W into v: v'[b] = sum_a v[a] W[(a,b)] for the b this lane group owns
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             double pb[RB];
 #pragma unroll
             for (int bi = 0; bi < RB; ++bi) pb[bi] = 0.0;
 #pragma unroll
-            for (int t = 0; t < TL; ++t)
+            for (int t = 0; t < TILES; ++t)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int u = 4 * t + i;
                     pb[u % RB] = __builtin_fma(v[nt][u / RB], acc[nt][t][i], pb[u % RB]);
                 }
 #pragma unroll
-            for (int b = 0; b < R; ++b) v[nt][b] = __shfl(pb[b >> 2], ((b & 3) << 4) | c16, 64);
-#pragma unroll
             for (int bi = 0; bi < RB; ++bi) vown[nt][bi] = pb[bi];
+            if (k < d - 2) spread(nt);
         }
-    };
-
-    if (d > 1) {   // dimension 0 (left rank 1): rows a = 0 only -> tiles covering R rows
-        constexpr int TL0 = (R + 15) / 16;
-        double sc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            double x = xs[(16 * nt + c16) * d + dims.col[0]];
-            sc[nt] = 2.0 * (x - dims.lo[0]) / (dims.hi[0] - dims.lo[0]) - 1.0;
-        }
-        pcx_d4 acc[NT][TL0];
-        tt_w_gemm<TL0, NT>(lds + plan.lds_off[0] + lane, plan.ks[0], g, sc, acc);
-        fold(acc, std::integral_constant<int, TL0>{});
-    }
-    for (int k = 1; k < d - 1; ++k) {
-        const double lo = dims.lo[k], hi = dims.hi[k];
-        double sc[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            double x = xs[(16 * nt + c16) * d + dims.col[k]];
-            sc[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;
-        }
-        pcx_d4 acc[NT][TILES];
-        tt_w_gemm<TILES, NT>(lds + plan.lds_off[k] + lane, plan.ks[k], g, sc, acc);
-        fold(acc, std::integral_constant<int, TILES>{});
     }
 
     // last dimension: y = sum_a v[a] * sum_j T_j(s) G[a][j]; lane group g takes a = g, g+4, ...
     {
-        const int k = d - 1;
-        const int n = dims.n[k];
-        const double lo = dims.lo[k], hi = dims.hi[k];
-        const double *gl = lds + plan.lds_off[k];
-        const int rl = plan.rl_last;
+        const double *gl = lds + plan.lds_off[d - 1] + g * NP;     // rows a = 4 bi + g
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-            long p = base + 16 * nt + c16;
-            double x = xs[(16 * nt + c16) * d + dims.col[k]];
-            double sc = 2.0 * (x - lo) / (hi - lo) - 1.0;
+            const long p = base + 16 * nt + c16;
+            const double sc = xs[(16 * nt + c16) * d + dims.col[d - 1]];
             double w[RB];
 #pragma unroll
             for (int bi = 0; bi < RB; ++bi) w[bi] = 0.0;
             double tp = 1.0, tc = sc;
-            for (int j = 0; j < n; ++j) {
+#pragma unroll
+            for (int j = 0; j < NP; ++j) {
                 const double q = tp;                       // T_j; (tp, tc) = (T_j, T_{j+1})
 #pragma unroll
-                for (int bi = 0; bi < RB; ++bi) {
-                    int a = 4 * bi + g;
-                    double gv = (a < rl) ? gl[a * n + j] : 0.0;
-                    w[bi] = __builtin_fma(q, gv, w[bi]);
-                }
+                for (int bi = 0; bi < RB; ++bi) w[bi] = __builtin_fma(q, gl[bi * 4 * NP + j], w[bi]);
                 const double tn = __builtin_fma(2.0 * sc, tc, -tp);
                 tp = tc;
                 tc = tn;
