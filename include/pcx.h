@@ -174,6 +174,17 @@ int pcx_tt_value_to_coeff_core(int device, const double *value_core, int rl, int
 int pcx_tt_grid_eval(int device, int d, const int32_t *n_nodes, const int32_t *ranks,
                      const double *value_cores_cat, const int32_t *idx, int count, double *out);
 
+/* TT-SVD compression of a dense C-order value tensor (d dims, n_nodes): replaces
+ * _tt_svd_from_tensor (tensor_train.py:638-690), used by ChebyshevTT.from_values (:2871-2965)
+ * and build(method="svd") (:1235-1243).  Each unfolding is factored on the device by a
+ * one-sided Jacobi iteration on its rows; the rank rule is the reference's (cap at
+ * max_rank, drop singular values <= tol * sigma_max, at least 1).  Outputs: ranks_out[d+1];
+ * the VALUE cores (r_{k-1}, n_k, r_k), C order, concatenated in cores_out (capacity
+ * cores_cap doubles, used length in *cores_len); sweeps_out (optional) = Jacobi sweeps run. */
+int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const double *tensor, int max_rank,
+               double tol, int32_t *ranks_out, double *cores_out, int64_t cores_cap,
+               int64_t *cores_len, int32_t *sweeps_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -402,6 +402,29 @@ def tt_cross(func, grids, max_rank, tol, max_sweeps, seed=None, trace=None):
 # TT finite-difference derivatives (tensor_train.py:2322-2463)
 # ----------------------------------------------------------------------------
 
+def tt_svd_from_tensor(tensor, max_rank: int, tol: float):
+    """tensor_train.py:638-690 (and the decomposition half of _tt_svd, :601-627): sequential
+    truncated SVDs of the unfoldings; rank = min(max_rank, len(S)) further capped by the
+    number of singular values > tol * S[0], never below 1.  Returns VALUE cores."""
+    T = np.asarray(tensor, dtype=np.float64)
+    n = list(T.shape)
+    d = len(n)
+    cores = []
+    C = T
+    r_prev = 1
+    for k in range(d - 1):
+        C = C.reshape(r_prev * n[k], -1)
+        U, S, Vt = np.linalg.svd(C, full_matrices=False)
+        rank = min(max_rank, len(S))
+        if S[0] > 0:
+            rank = max(1, min(rank, int(np.sum(S > tol * S[0]))))
+        cores.append(U[:, :rank].reshape(r_prev, n[k], rank))
+        C = np.diag(S[:rank]) @ Vt[:rank, :]
+        r_prev = rank
+    cores.append(C.reshape(r_prev, n[d - 1], 1))
+    return cores
+
+
 def tt_eval_multi(coeff_cores, domain, point, derivative_orders, dim_order=None):
     """eval_multi semantics: permute once into storage frame, value specs through the
     core chain, derivative specs through the central-difference rules."""

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpcx_hip.so")
 SOURCES = ["pcx_api.hip"]
-HEADERS = ["pcx_common.h", "bary_kernels.h", "tt_kernels.h", "ttcross_kernels.h",
+HEADERS = ["pcx_common.h", "bary_kernels.h", "tt_kernels.h", "ttcross_kernels.h", "ttsvd_kernels.h",
            os.path.join("..", "..", "include", "pcx.h")]
 ARCH = "gfx950"
 

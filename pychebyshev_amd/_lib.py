@@ -86,6 +86,7 @@ SIGNATURES = {
     "pcx_maxvol": (_I, [_I, c_f64p, _I, _I, _D, _I, c_i64p]),
     "pcx_tt_value_to_coeff_core": (_I, [_I, c_f64p, _I, _I, _I, c_f64p]),
     "pcx_tt_grid_eval": (_I, [_I, _I, c_i32p, c_i32p, c_f64p, c_i32p, _I, c_f64p]),
+    "pcx_tt_svd": (_I, [_I, _I, c_i32p, c_f64p, _I, _D, c_i32p, c_f64p, _L, c_i64p, c_i32p]),
 }
 
 _LIB = None

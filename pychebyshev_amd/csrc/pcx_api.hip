@@ -17,6 +17,7 @@
 #include "bary_kernels.h"
 #include "tt_kernels.h"
 #include "ttcross_kernels.h"
+#include "ttsvd_kernels.h"
 
 // ---------------------------------------------------------------------------------
 // errors
@@ -1302,6 +1303,98 @@ extern "C" int pcx_tt_grid_eval(int device, int d, const int32_t *n_nodes, const
                        dout.as<double>(), dwork.as<double>(), rmax);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpy(out, dout.p, (size_t)count * sizeof(double), hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+
+// TT-SVD of a dense value tensor (reference _tt_svd_from_tensor, tensor_train.py:638-690).
+extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const double *tensor, int max_rank,
+                          double tol, int32_t *ranks_out, double *cores_out, int64_t cores_cap,
+                          int64_t *cores_len, int32_t *sweeps_out) {
+    if (d < 1 || d > PCX_MAX_DIMS || !n_nodes || !tensor || !ranks_out || !cores_out || !cores_len)
+        return fail(PCX_ERR_INVALID, "bad argument");
+    if (max_rank < 1) return fail(PCX_ERR_INVALID, "max_rank must be >= 1");
+    long total = 1;
+    for (int k = 0; k < d; ++k) {
+        if (n_nodes[k] < 1) return fail(PCX_ERR_INVALID, "n_nodes[%d] < 1", k);
+        total *= n_nodes[k];
+        if (total > (1L << 33)) return fail(PCX_ERR_UNSUPPORTED, "dense tensor too large for TT-SVD");
+    }
+    int rc = use_device(device);
+    if (rc) return rc;
+    DevBuf cur, nxt, dU, dnorm, drot, drows;
+    if ((rc = cur.alloc((size_t)total * sizeof(double)))) return rc;
+    if ((rc = nxt.alloc((size_t)total * sizeof(double)))) return rc;
+    if ((rc = drot.alloc(sizeof(int)))) return rc;
+    HIP_TRY(hipMemcpy(cur.p, tensor, (size_t)total * sizeof(double), hipMemcpyHostToDevice));
+    long elems = total;
+    int r_prev = 1;
+    int64_t written = 0;
+    int sweeps_total = 0;
+    ranks_out[0] = 1;
+    std::vector<double> hU, hnorm;
+    std::vector<int> order;
+    for (int k = 0; k < d - 1; ++k) {
+        const long m_l = (long)r_prev * n_nodes[k];
+        if (m_l > 8192) return fail(PCX_ERR_UNSUPPORTED, "TT-SVD unfolding with %ld rows (> 8192)", m_l);
+        const int m = (int)m_l;
+        const long N = elems / m;
+        DevBuf U, nrm, rows;
+        if ((rc = U.alloc((size_t)m * m * sizeof(double)))) return rc;
+        if ((rc = nrm.alloc((size_t)m * sizeof(double)))) return rc;
+        if ((rc = rows.alloc((size_t)m * sizeof(int)))) return rc;
+        hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((long)m * m + 255) / 256)), dim3(256), 0, 0, U.as<double>(), m);
+        const int mp = (m + 1) & ~1;
+        if (m > 1) {
+            for (int sweep = 0; sweep < 60; ++sweep) {
+                HIP_TRY(hipMemsetAsync(drot.p, 0, sizeof(int), 0));
+                for (int step = 0; step < mp - 1; ++step)
+                    hipLaunchKernelGGL(k_rowjacobi_step, dim3(mp / 2), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, m, N,
+                                       U.as<double>(), step, drot.as<int>());
+                HIP_TRY(hipGetLastError());
+                int rotated = 0;
+                HIP_TRY(hipMemcpy(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost));
+                ++sweeps_total;
+                if (rotated == 0) break;
+            }
+        }
+        hipLaunchKernelGGL(k_row_sqnorms, dim3(m), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, N, nrm.as<double>());
+        HIP_TRY(hipGetLastError());
+        hnorm.resize(m);
+        HIP_TRY(hipMemcpy(hnorm.data(), nrm.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+        order.resize(m);
+        for (int i = 0; i < m; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return hnorm[a] > hnorm[b]; });
+        // rank rule of the reference (:673-678): cap, then drop S <= tol * S[0]
+        const long len_s = std::min<long>(m, N);
+        int rank = (int)std::min<long>(max_rank, len_s);
+        const double s0 = std::sqrt(hnorm[order[0]]);
+        if (s0 > 0.0) {
+            int effective = 0;
+            for (int i = 0; i < len_s; ++i) effective += (std::sqrt(hnorm[order[i]]) > tol * s0) ? 1 : 0;
+            rank = std::max(1, std::min(rank, effective));
+        }
+        if (written + (int64_t)m * rank > cores_cap) return fail(PCX_ERR_INVALID, "cores_out too small");
+        hU.resize((size_t)m * m);
+        HIP_TRY(hipMemcpy(hU.data(), U.p, (size_t)m * m * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < m; ++i)
+            for (int c = 0; c < rank; ++c) cores_out[written + (int64_t)i * rank + c] = hU[(size_t)i * m + order[c]];
+        written += (int64_t)m * rank;
+        HIP_TRY(hipMemcpy(rows.p, order.data(), (size_t)rank * sizeof(int), hipMemcpyHostToDevice));
+        unsigned gx = (unsigned)std::min<long>((N + 255) / 256, 1024);
+        hipLaunchKernelGGL(k_gather_rows, dim3(gx, rank), dim3(256), 0, 0, cur.as<double>(), N, N, rows.as<int>(), nxt.as<double>());
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipDeviceSynchronize());
+        std::swap(cur.p, nxt.p);
+        elems = (long)rank * N;
+        r_prev = rank;
+        ranks_out[k + 1] = rank;
+    }
+    ranks_out[d] = 1;
+    if (written + elems > cores_cap) return fail(PCX_ERR_INVALID, "cores_out too small");
+    HIP_TRY(hipMemcpy(cores_out + written, cur.p, (size_t)elems * sizeof(double), hipMemcpyDeviceToHost));
+    written += elems;
+    *cores_len = written;
+    if (sweeps_out) *sweeps_out = sweeps_total;
     return PCX_OK;
 }
 

@@ -16,7 +16,7 @@ DCT -- runs on the device (``pcx_tt_cross_step``, ``pcx_tt_grid_eval``,
 ``pcx_tt_value_to_coeff_core``).  Evaluation (single, batch, finite-difference stencils)
 is always a ``pcx_tt_eval_batch`` launch; there is no CPU fallback.
 
-Out of scope in this tier (raise ``NotImplementedError``): ``method='svd'`` / ``'als'``
+Out of scope in this tier (raise ``NotImplementedError``): ``method='als'``
 builders, algebra, calculus, slicing, reordering, Sobol indices.
 """
 from __future__ import annotations
@@ -96,6 +96,55 @@ def _tt_grid_values(cores: Sequence[np.ndarray], idx: np.ndarray) -> np.ndarray:
     _lib.check(lib.pcx_tt_grid_eval(_device(), d, _lib.p_i32(n), _lib.p_i32(ranks), _lib.p_f64(cat),
                                     _lib.p_i32(ii), ii.shape[0], _lib.p_f64(out)), lib)
     return out
+
+
+def _tt_svd_from_tensor(tensor: np.ndarray, max_rank: int, tol: float) -> List[np.ndarray]:
+    """TT-SVD of a dense value tensor (reference tensor_train.py:638-690): value cores
+    ``(r_{k-1}, n_k, r_k)``.  Every unfolding is factored on the device (one-sided Jacobi on
+    its rows, ``pcx_tt_svd``); the rank rule is the reference's."""
+    lib = _lib.load()
+    t = _lib.f64(np.asarray(tensor, dtype=np.float64))
+    n = [int(v) for v in t.shape]
+    d = len(n)
+    if d == 1:
+        return [t.reshape(1, n[0], 1).copy()]
+    cap = 0
+    r_prev, rest = 1, int(np.prod(n))
+    for k in range(d):
+        rest //= n[k]
+        r = 1 if k == d - 1 else min(int(max_rank), r_prev * n[k], rest)
+        cap += r_prev * n[k] * r
+        r_prev = r
+    cores_cat = np.empty(cap)
+    ranks = np.zeros(d + 1, dtype=np.int32)
+    used = ctypes.c_int64(0)
+    sweeps = ctypes.c_int32(0)
+    _lib.check(lib.pcx_tt_svd(_device(), d, _lib.p_i32(_lib.i32(n)), _lib.p_f64(t.ravel()), int(max_rank),
+                              float(tol), _lib.p_i32(ranks), _lib.p_f64(cores_cat), cap,
+                              ctypes.byref(used), ctypes.byref(sweeps)), lib)
+    cores, off = [], 0
+    for k in range(d):
+        cnt = int(ranks[k]) * n[k] * int(ranks[k + 1])
+        cores.append(cores_cat[off: off + cnt].reshape(int(ranks[k]), n[k], int(ranks[k + 1])).copy())
+        off += cnt
+    return cores
+
+
+def _tt_svd(func, grids, max_rank, tol, verbose):
+    """Full-grid evaluation through the Python callback (C order, as the reference's
+    ``np.ndindex`` loop, :594-599) followed by the device TT-SVD (reference :543-635)."""
+    n = [len(g) for g in grids]
+    full = int(np.prod(n))
+    if verbose:
+        print(f"  Building full tensor ({full:,} evaluations)...")
+    T = np.empty(n)
+    d = len(n)
+    for idx in np.ndindex(*n):
+        T[idx] = func([float(grids[k][idx[k]]) for k in range(d)], None)
+    cores = _tt_svd_from_tensor(T, max_rank, tol)
+    if verbose:
+        print(f"  TT-SVD ranks: {[1] + [c.shape[2] for c in cores]}")
+    return cores, full
 
 
 # --------------------------------------------------------------------------------------
@@ -330,9 +379,10 @@ class ChebyshevTT:
         """TT-Cross build then value->coefficient conversion (reference :1140-1289)."""
         if method not in ("cross", "svd", "als"):
             raise ValueError(f"method must be 'cross', 'svd', or 'als', got {method!r}")
-        if method != "cross":
-            raise NotImplementedError(f"method={method!r} builds the full tensor on the host with "
-                                      "LAPACK in the reference; only 'cross' is in this build's scope")
+        if method == "als":
+            raise NotImplementedError("method='als' (alternating least squares sweeps around LAPACK "
+                                      "solves in the reference) is outside this build's scope; "
+                                      "use 'cross' or 'svd'")
         self.method = method
         start = time.time()
         self._cached_error_estimate = None
@@ -347,10 +397,13 @@ class ChebyshevTT:
         def with_data(point, _unused):
             return raw(point, data)
 
-        if verbose:
-            print("  Running TT-Cross...")
-        value_cores, n_evals = _tt_cross(with_data, grids, self.max_rank, self.tolerance,
-                                         self.max_sweeps, verbose, seed)
+        if method == "cross":
+            if verbose:
+                print("  Running TT-Cross...")
+            value_cores, n_evals = _tt_cross(with_data, grids, self.max_rank, self.tolerance,
+                                             self.max_sweeps, verbose, seed)
+        else:
+            value_cores, n_evals = _tt_svd(with_data, grids, self.max_rank, self.tolerance, verbose)
         self._total_build_evals = n_evals
         self._coeff_cores = [_value_core_to_coeff_core(c) for c in value_cores]
         self._tt_ranks = [1] + [c.shape[2] for c in self._coeff_cores]
@@ -362,6 +415,37 @@ class ChebyshevTT:
             print(f"  Built in {self._build_time:.3f}s ({n_evals:,} function evaluations)")
             print(f"  TT ranks: {self._tt_ranks}")
             print(f"  Compression: {full:,} -> {storage:,} elements ({full / storage:.1f}x)")
+
+    @classmethod
+    def from_values(cls, tensor_values, num_dimensions: int, domain, n_nodes,
+                    max_rank: int | None = None, tolerance: float = 1e-6,
+                    max_derivative_order: int = 2, additional_data=None,
+                    descriptor: str = "") -> "ChebyshevTT":
+        """TT interpolant from a precomputed dense tensor of node values by TT-SVD
+        (reference :2871-2965); the compression runs on the device."""
+        from . import Domain, Ns
+        if isinstance(domain, Domain):
+            domain = list(domain.bounds)
+        if isinstance(n_nodes, Ns):
+            n_nodes = list(n_nodes.counts)
+        arr = np.asarray(tensor_values, dtype=np.float64)
+        expected_shape = tuple(n_nodes)
+        if arr.shape != expected_shape:
+            raise ValueError(f"tensor_values shape {arr.shape} does not match expected {expected_shape}")
+        if not np.isfinite(arr).all():
+            raise ValueError("tensor_values contains NaN or Inf — all values must be finite")
+        if max_rank is None:
+            max_rank = max(n_nodes)
+        value_cores = _tt_svd_from_tensor(arr, max_rank=max_rank, tol=tolerance)
+        obj = cls(None, num_dimensions, list(domain), list(n_nodes), max_rank=max_rank,
+                  tolerance=tolerance, max_derivative_order=max_derivative_order,
+                  additional_data=additional_data)
+        obj.descriptor = descriptor
+        obj.method = "svd"
+        obj._coeff_cores = [_value_core_to_coeff_core(c) for c in value_cores]
+        obj._tt_ranks = [c.shape[0] for c in obj._coeff_cores] + [obj._coeff_cores[-1].shape[2]]
+        obj._built = True
+        return obj
 
     @classmethod
     def from_coeff_cores(cls, coeff_cores: Sequence[np.ndarray], domain, dim_order=None,

@@ -69,6 +69,16 @@ def sin_sum_nd(x, _=None):
     return sum(math.sin(v) for v in x)
 
 
+def exp_mix_3d(x, _=None):
+    """Smooth, non-separable 3-D function (TT ranks > 2 at tight tolerances)."""
+    return math.exp(-0.5 * (x[0] - 0.3 * x[1]) ** 2) * math.cos(x[1] * x[2]) + 0.1 * x[0] * x[2]
+
+
+def separable4(x, _=None):
+    """Rank-1 4-D product: every TT-SVD unfolding is rank deficient."""
+    return (1.0 + x[0]) * math.exp(x[1]) * (2.0 - x[2] ** 2) * math.cos(x[3])
+
+
 def poly_5d_fixture(x, _=None):
     """f of the reference's approx_5d_bs.pcb fixture (scripts/generate_test_fixtures.py there)."""
     return math.sin(x[0]) + math.cos(x[1]) + x[2] ** 2 + x[3] * x[4]

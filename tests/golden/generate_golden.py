@@ -19,6 +19,8 @@ Sets:
   g6_primitives    nodes / weights / diff matrices / maxvol / value->coeff transform
   g7_tt_small      TT-Cross on 3-D sin-sum and 10-D sin-sum (ranks, evals, values)
   g8_small_bary    small odd-shaped barycentric cases incl. exact-node and edge points
+  g9..g11          splines, sliders, slice/integrate (rows f2, f4, f3)
+  g12_tt_svd       TT-SVD: from_values on the 5-D BS tensor, build(method="svd") on small cases
 """
 from __future__ import annotations
 
@@ -35,7 +37,12 @@ sys.path.insert(0, HERE)
 import functions as F  # noqa: E402
 
 
+ONLY: set = set()
+
+
 def save(name, **arrays):
+    if ONLY and name.split("_")[0] not in ONLY:
+        return
     path = os.path.join(HERE, name + ".npz")
     np.savez_compressed(path, **arrays)
     print(f"  wrote {name}.npz ({os.path.getsize(path) / 1024:.1f} KiB)")
@@ -44,7 +51,9 @@ def save(name, **arrays):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="", help="comma list of set prefixes to (re)write, e.g. g12")
     args = ap.parse_args()
+    ONLY.update(x for x in args.only.split(",") if x)
     sys.path.insert(0, os.path.join(args.ref, "src"))
     import pychebyshev as ref
     from pychebyshev import ChebyshevApproximation, ChebyshevTT
@@ -359,6 +368,30 @@ def main():
     for n_ in (2, 5, 11, 12, 33):
         g11[f"fejer{n_}"] = _compute_fejer1_weights(n_)
     save("g11_slice", params_c_value=np.array(node_val), **g11)
+
+    # ---------------------------------------------------------------- g12 (TT-SVD, row f4)
+    g12 = {}
+    svd_pts = F.bs5_query_points(2048, seed=99)
+    for tag, (mr, tol_) in {"r8": (8, 1e-6), "rdef": (None, 1e-8), "r3": (3, 1e-12)}.items():
+        tts = ChebyshevTT.from_values(bs.tensor_values, 5, F.BS5_DOMAIN, [11] * 5, max_rank=mr, tolerance=tol_)
+        g12[f"bs_{tag}_ranks"] = np.array(tts.tt_ranks)
+        g12[f"bs_{tag}_eval"] = tts.eval_batch(svd_pts)
+    g12["bs_points"] = svd_pts
+    small = {
+        "mix3": dict(f=F.exp_mix_3d, d=3, dom=[[-1, 1], [0, 2], [-2, 1]], n=[9, 10, 11], mr=6, tol=1e-10),
+        "sep4": dict(f=F.separable4, d=4, dom=[[0, 1]] * 4, n=[4, 5, 3, 6], mr=5, tol=1e-9),
+        "wide2": dict(f=F.sin_cos_2d, d=2, dom=[[-1, 1], [-1, 1]], n=[14, 5], mr=10, tol=1e-12),
+    }
+    for tag, c in small.items():
+        tts = ChebyshevTT(c["f"], c["d"], c["dom"], c["n"], max_rank=c["mr"], tolerance=c["tol"])
+        tts.build(verbose=False, method="svd")
+        rng_ = np.random.default_rng(5)
+        pts_ = np.column_stack([rng_.uniform(lo, hi, 300) for lo, hi in c["dom"]])
+        g12[f"{tag}_ranks"] = np.array(tts.tt_ranks)
+        g12[f"{tag}_evals"] = np.array(tts.total_build_evals)
+        g12[f"{tag}_points"] = pts_
+        g12[f"{tag}_eval"] = tts.eval_batch(pts_)
+    save("g12_tt_svd", **g12)
 
     print(f"done in {time.time() - t0:.1f}s")
 

@@ -291,3 +291,65 @@ def test_points_outside_the_domain_extrapolate_like_the_reference_algorithm(orac
         _set_tt_kernel(tt, variant)
         y = tt.eval_batch(pts)
         assert np.max(np.abs(y - ref)) <= 1e-11 * np.max(np.abs(ref)), variant
+
+
+# ------------------------------------------------------------------ TT-SVD (row f4)
+@pytest.mark.parametrize("tag,mr,tol", [("r8", 8, 1e-6), ("rdef", None, 1e-8), ("r3", 3, 1e-12)])
+def test_from_values_tt_svd_matches_reference(tag, mr, tol):
+    g = golden("g12_tt_svd")
+    bs = golden("g2_bs5d")["tensor"]
+    tt = ChebyshevTT.from_values(bs, 5, F.BS5_DOMAIN, [11] * 5, max_rank=mr, tolerance=tol)
+    assert tt.tt_ranks == list(g[f"bs_{tag}_ranks"])
+    assert tt.method == "svd" and tt.function is None and tt.total_build_evals == 0
+    # the truncated tensor is unique (singular subspaces), the cores are not: compare values
+    assert_parity(tt.eval_batch(g["bs_points"]), g[f"bs_{tag}_eval"], 1e-9, f"from_values {tag}")
+
+
+def test_tt_svd_value_cores_reproduce_the_tensor_and_are_orthonormal():
+    rng = np.random.default_rng(3)
+    T = rng.standard_normal((6, 5, 7, 4))
+    cores = tt_mod._tt_svd_from_tensor(T, max_rank=64, tol=0.0)     # no truncation: exact
+    full = cores[0]
+    for c in cores[1:]:
+        full = np.tensordot(full, c, axes=([-1], [0]))
+    assert np.max(np.abs(full.reshape(T.shape) - T)) < 1e-13
+    for c in cores[:-1]:                                              # left-orthonormal cores
+        m = c.reshape(-1, c.shape[2])
+        assert np.max(np.abs(m.T @ m - np.eye(m.shape[1]))) < 1e-13
+    # singular values of the first unfolding = row norms of the remainder, descending
+    s_ref = np.linalg.svd(T.reshape(6, -1), compute_uv=False)
+    rest = cores[1]
+    for c in cores[2:]:
+        rest = np.tensordot(rest, c, axes=([-1], [0]))
+    s = np.linalg.norm(rest.reshape(rest.shape[0], -1), axis=1)
+    assert np.allclose(s, s_ref, rtol=1e-12, atol=0)
+
+
+def test_build_method_svd_matches_reference(capsys):
+    g = golden("g12_tt_svd")
+    cases = {
+        "mix3": dict(f=F.exp_mix_3d, d=3, dom=[[-1, 1], [0, 2], [-2, 1]], n=[9, 10, 11], mr=6, tol=1e-10),
+        "sep4": dict(f=F.separable4, d=4, dom=[[0, 1]] * 4, n=[4, 5, 3, 6], mr=5, tol=1e-9),
+        "wide2": dict(f=F.sin_cos_2d, d=2, dom=[[-1, 1], [-1, 1]], n=[14, 5], mr=10, tol=1e-12),
+    }
+    for tag, c in cases.items():
+        tt = ChebyshevTT(c["f"], c["d"], c["dom"], c["n"], max_rank=c["mr"], tolerance=c["tol"])
+        tt.build(verbose=(tag == "mix3"), method="svd")
+        assert tt.tt_ranks == list(g[f"{tag}_ranks"]) and tt.total_build_evals == int(g[f"{tag}_evals"])
+        assert_parity(tt.eval_batch(g[f"{tag}_points"]), g[f"{tag}_eval"], 1e-9, f"svd build {tag}")
+    out = capsys.readouterr().out
+    assert "method='svd'" in out and "Building full tensor (990 evaluations)..." in out
+    assert "TT-SVD ranks: [1, 6, 6, 1]" in out
+
+
+def test_from_values_validation():
+    with pytest.raises(ValueError, match="shape"):
+        ChebyshevTT.from_values(np.zeros((3, 4)), 2, [[0, 1], [0, 1]], [4, 3])
+    bad = np.ones((3, 4))
+    bad[1, 1] = np.nan
+    with pytest.raises(ValueError, match="finite"):
+        ChebyshevTT.from_values(bad, 2, [[0, 1], [0, 1]], [3, 4])
+    tt = ChebyshevTT.from_values(np.zeros((3, 4)), 2, [[0, 1], [0, 1]], [3, 4])   # all-zero tensor
+    assert tt.eval([0.3, 0.4]) == 0.0
+    one = ChebyshevTT.from_values(np.arange(5.0), 1, [[0, 1]], [5])                # 1-D: single core
+    assert one.tt_ranks == [1, 1]

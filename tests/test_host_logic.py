@@ -219,7 +219,7 @@ def test_tt_constructor_errors_and_properties():
     with pytest.raises(ValueError, match="'cross', 'svd', or 'als'"):
         tt.build(verbose=False, method="qr")
     with pytest.raises(NotImplementedError):
-        tt.build(verbose=False, method="svd")
+        tt.build(verbose=False, method="als")
     cores = [np.ones((1, 4, 2)), np.ones((2, 3, 1))]
     w = ChebyshevTT.from_coeff_cores(cores, [[0, 1], [0, 2]], dim_order=[1, 0])
     assert w.tt_ranks == [1, 2, 1] and w.dim_order == [1, 0] and w.n_nodes == [4, 3]

@@ -223,3 +223,15 @@ def test_tt_cross_restatement_small(oracle_mod):
     assert [1] + [c.shape[2] for c in vc] == list(g["x_ranks"]) and nev == int(g["x_evals"])
     y = o.tt_eval_batch([o.value_to_coeff_core(c) for c in vc], F.BS5_DOMAIN, g["x_points"])
     assert_parity(y, g["x_eval"], 1e-9, "capped BS")
+
+
+def test_tt_svd_restatement(oracle_mod):
+    """TT-SVD (row f4): ranks equal to the reference's, values to 1e-10 (cores themselves are
+    only defined up to a sign/rotation of the singular vectors)."""
+    o, g = oracle_mod, golden("g12_tt_svd")
+    bs = golden("g2_bs5d")["tensor"]
+    for tag, (mr, tol) in {"r8": (8, 1e-6), "rdef": (11, 1e-8), "r3": (3, 1e-12)}.items():
+        vc = o.tt_svd_from_tensor(bs, mr, tol)
+        assert [1] + [c.shape[2] for c in vc] == list(g[f"bs_{tag}_ranks"])
+        y = o.tt_eval_batch([o.value_to_coeff_core(c) for c in vc], F.BS5_DOMAIN, g["bs_points"])
+        assert_parity(y, g[f"bs_{tag}_eval"], 1e-10, f"TT-SVD BS {tag}")
