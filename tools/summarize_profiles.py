@@ -38,11 +38,13 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--sq")
+    ap.add_argument("--sq2", help="optional second SQ pass (instruction mix, LDS)")
+    ap.add_argument("--tag", default="", help="suffix for the output names, e.g. _v3")
     a = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
-    tag = f"{a.round}_{a.workload}"
+    tag = f"{a.round}_{a.workload}{a.tag}"
     summary = {"workload": a.workload, "kernel": a.kernel, "points_per_launch": a.points}
     if a.kt:
         for f in glob.glob(os.path.join(a.kt, "*kernel_stats.csv")):
@@ -63,7 +65,7 @@ def main():
                               "hbm_bytes_per_launch": fetch_b + write_b, "dispatches_averaged": fs[1]}
             tpath = os.path.join(out, "pmc_traffic.json")
             table = json.load(open(tpath)) if os.path.exists(tpath) else {}
-            table[a.workload] = {"points": a.points, "hbm_bytes_per_launch": fetch_b + write_b,
+            table[a.workload + a.tag] = {"points": a.points, "hbm_bytes_per_launch": fetch_b + write_b,
                                  "source": f"profiles/{tag}_summary.json"}
             json.dump(table, open(tpath, "w"), indent=1)
     if a.sq:
@@ -77,6 +79,10 @@ def main():
             summary["mfma_util_percent"] = 100.0 * sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024)
             if "kernel_trace" in summary:
                 summary["effective_clock_ghz"] = sq["GRBM_GUI_ACTIVE"] / 8 / summary["kernel_trace"]["avg_ns"]
+    if a.sq2 and os.path.isdir(a.sq2):
+        c = counters(a.sq2, a.kernel)
+        if c:
+            summary["sq_mix"] = {k: v[0] for k, v in c.items()}
     json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
