@@ -20,5 +20,9 @@ timeout -k 10 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_A
 timeout -k 10 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT \
     -d "$OUT/sq2" -o p --output-format csv -- python3 $ARGS > "$OUT/sq2.log" 2>&1 || echo "second SQ pass failed (counter names?)"
 cd "$ROOT"
+# gpurun merges only gpurun_out/ back: summarise there too, and re-run the summariser in the
+# build container to (re)write profiles/:
+#   O=gpurun_out/prof_$WL$TAG; python3 tools/summarize_profiles.py --round R --workload W --kernel K --points N \
+#       --kt $O/kt --fetch $O/fetch --write $O/write --sq $O/sq --sq2 $O/sq2 --tag "$TAG"
 python3 tools/summarize_profiles.py --round "$ROUND" --workload "$WL" --kernel "$KERNEL" --points "$POINTS" \
-    --kt "$OUT/kt" --fetch "$OUT/fetch" --write "$OUT/write" --sq "$OUT/sq" --sq2 "$OUT/sq2" --tag "$TAG"
+    --kt "$OUT/kt" --fetch "$OUT/fetch" --write "$OUT/write" --sq "$OUT/sq" --sq2 "$OUT/sq2" --tag "$TAG" --out "$OUT"

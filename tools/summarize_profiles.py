@@ -40,9 +40,10 @@ def main():
     ap.add_argument("--sq")
     ap.add_argument("--sq2", help="optional second SQ pass (instruction mix, LDS)")
     ap.add_argument("--tag", default="", help="suffix for the output names, e.g. _v3")
+    ap.add_argument("--out", default="", help="output directory (default: <repo>/profiles)")
     a = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    out = os.path.join(root, "profiles")
+    out = a.out or os.path.join(root, "profiles")
     os.makedirs(out, exist_ok=True)
     tag = f"{a.round}_{a.workload}{a.tag}"
     summary = {"workload": a.workload, "kernel": a.kernel, "points_per_launch": a.points}
