@@ -238,6 +238,10 @@ def main():
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     os.environ["PCX_DEVICE"] = str(local_rank)
+    if world == 1:
+        from pychebyshev_amd import _build
+        if _build.needs_build():          # fresh checkout: the .so is git-ignored
+            _build.build()
     lib = _lib.load()
     dev = local_rank
 

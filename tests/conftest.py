@@ -16,6 +16,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+@pytest.fixture(scope="session", autouse=True)
+def _hip_library_is_current():
+    """(Re)build libpcx_hip.so when it is missing or older than its sources: hipcc
+    cross-compiles without a GPU, so this works in the build container and on the GPU box."""
+    from pychebyshev_amd import _build
+    if _build.needs_build():
+        _build.build()
+
+
 def golden(name):
     return np.load(os.path.join(GOLDEN, name + ".npz"))
 
