@@ -22,6 +22,7 @@ auto-N, algebra/calculus/extrude/slice.
 from __future__ import annotations
 
 import ctypes
+import math
 import os
 import pickle
 import time
@@ -679,7 +680,73 @@ class ChebyshevApproximation(DerivativeIdMixin):
         from . import _binary
         return _binary.peek_format_version(filename)
 
+    # ---------------------------------------------------------------- error estimate
+    @staticmethod
+    def _last_coefficient_vector(n: int) -> np.ndarray:
+        """q with ``c_{n-1} = q . values`` for values at ascending type-I nodes: row n-1 of the
+        DCT-II the reference applies to the reversed values, divided by n (and halved when it
+        is also row 0, n = 1)."""
+        j = np.arange(n)[::-1]
+        q = 2.0 * np.cos(math.pi * (n - 1) * (2 * j + 1) / (2.0 * n)) / n
+        return q / 2.0 if n == 1 else q
+
+    @staticmethod
+    def _chebyshev_coefficients_1d(values: np.ndarray) -> np.ndarray:
+        """Chebyshev coefficients of values at ascending type-I nodes (reference :1250-1276:
+        DCT-II of the reversed values / n, c_0 halved), as one small host matrix product."""
+        v = np.asarray(values, dtype=float)[::-1]
+        n = len(v)
+        k = np.arange(n)[:, None]
+        j = np.arange(n)[None, :]
+        c = (2.0 * np.cos(math.pi * k * (2 * j + 1) / (2.0 * n)) @ v) / n
+        c[0] /= 2.0
+        return c
+
+    def _error_estimate_per_dim(self) -> List[float]:
+        """Per dimension, the largest |last Chebyshev coefficient| over all 1-D slices
+        (reference :1278-1308).  The last coefficient of every slice along axis k is ONE mode
+        product of the tensor with a fixed vector: a device contraction per dimension."""
+        if self.tensor_values is None:
+            raise RuntimeError("Call build() first")
+        return [float(np.max(np.abs(self._contract(self.tensor_values, k, self._last_coefficient_vector(n)))))
+                for k, n in enumerate(self.n_nodes)]
+
+    def error_estimate(self) -> float:
+        """Sum over dimensions of the largest last-coefficient magnitude (reference :1310-1341;
+        Ruiz & Zeron 2021, ex ante error estimation)."""
+        if self._cached_error_estimate is None:
+            self._cached_error_estimate = float(sum(self._error_estimate_per_dim()))
+        return self._cached_error_estimate
+
+    def fast_eval(self, point, derivative_order=None, *, derivative_id=None) -> float:
+        """Deprecated alias kept for drop-in compatibility (reference :789-869): same value as
+        :meth:`vectorized_eval`, which it asks callers to use instead."""
+        warnings.warn("fast_eval() is deprecated and will be removed in a future version. "
+                      "Use vectorized_eval() instead.", DeprecationWarning, stacklevel=2)
+        return self.vectorized_eval(point, derivative_order, derivative_id=derivative_id)
+
     # ---------------------------------------------------------------- printing
     def __repr__(self) -> str:
         return (f"ChebyshevApproximation(dims={self.num_dimensions}, nodes={self.n_nodes}, "
                 f"built={self.tensor_values is not None})")
+
+    def __str__(self) -> str:
+        """Multi-line summary in the reference's layout (:2512-2556)."""
+        built = self.tensor_values is not None
+        shown = 6                                   # dimensions listed before the ellipsis
+        ns, dom = list(self.n_nodes), list(self.domain)
+        if self.num_dimensions > shown:
+            nodes_txt = "[" + ", ".join(str(n) for n in ns[:shown]) + ", ...]"
+            dom_txt = " x ".join(f"[{lo}, {hi}]" for lo, hi in dom[:shown]) + " x ..."
+        else:
+            nodes_txt = str(ns)
+            dom_txt = " x ".join(f"[{lo}, {hi}]" for lo, hi in dom)
+        total_txt = "auto" if any(n is None for n in ns) else f"{int(np.prod(ns)):,}"
+        out = [f"ChebyshevApproximation ({self.num_dimensions}D, {'built' if built else 'not built'})",
+               f"  Nodes:       {nodes_txt} ({total_txt} total)",
+               f"  Domain:      {dom_txt}"]
+        if built:
+            out.append(f"  Build:       {self.build_time:.3f}s, {self.n_evaluations:,} evaluations")
+            out.append(f"  Error est:   {self.error_estimate():.2e}")
+        out.append(f"  Derivatives: up to order {self.max_derivative_order}")
+        return "\n".join(out)

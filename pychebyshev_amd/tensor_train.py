@@ -696,3 +696,27 @@ class ChebyshevTT:
     def __repr__(self) -> str:
         return (f"ChebyshevTT(dims={self.num_dimensions}, nodes={self.n_nodes}, "
                 f"max_rank={self.max_rank}, built={self._built})")
+
+    def __str__(self) -> str:
+        """Multi-line summary in the reference's layout (:3235-3281)."""
+        shown = 6
+        ns, dom = list(self.n_nodes), list(self.domain)
+        if self.num_dimensions > shown:
+            nodes_txt = "[" + ", ".join(str(n) for n in ns[:shown]) + ", ...]"
+            dom_txt = " x ".join(f"[{lo}, {hi}]" for lo, hi in dom[:shown]) + " x ..."
+        else:
+            nodes_txt = str(ns)
+            dom_txt = " x ".join(f"[{lo}, {hi}]" for lo, hi in dom)
+        out = [f"ChebyshevTT ({self.num_dimensions}D, {'built' if self._built else 'not built'})",
+               f"  Nodes:       {nodes_txt}"]
+        if self._built:
+            full = int(np.prod(ns))
+            stored = sum(c.size for c in self._coeff_cores)
+            out += [f"  TT ranks:    {self._tt_ranks}",
+                    f"  Compression: {full:,} -> {stored:,} elements ({full / stored:.1f}x)",
+                    f"  Build:       {self._build_time:.3f}s ({self._total_build_evals:,} function evals)",
+                    f"  Domain:      {dom_txt}",
+                    f"  Error est:   {self.error_estimate():.2e}"]
+        else:
+            out.append(f"  Domain:      {dom_txt}")
+        return "\n".join(out)

@@ -21,6 +21,7 @@ Sets:
   g8_small_bary    small odd-shaped barycentric cases incl. exact-node and edge points
   g9..g11          splines, sliders, slice/integrate (rows f2, f4, f3)
   g12_tt_svd       TT-SVD: from_values on the 5-D BS tensor, build(method="svd") on small cases
+  g13_estimates    error_estimate() / per-dimension values, str() of built and unbuilt objects
 """
 from __future__ import annotations
 
@@ -392,6 +393,28 @@ def main():
         g12[f"{tag}_points"] = pts_
         g12[f"{tag}_eval"] = tts.eval_batch(pts_)
     save("g12_tt_svd", **g12)
+
+    # ---------------------------------------------------------------- g13 (error estimates, str())
+    g13 = {"bs_per_dim": np.array(bs._error_estimate_per_dim()), "bs_total": np.array(bs.error_estimate()),
+           "bs_str": np.array(str(bs))}
+    rng13 = np.random.default_rng(13)
+    for tag, shape in {"a": (7,), "b": (1, 5), "c": (4, 1, 6), "d": (3, 8, 2, 5)}.items():
+        vals = rng13.standard_normal(shape)
+        dom13 = [[-1.0, 2.0]] * len(shape)
+        ob = ChebyshevApproximation.from_values(vals, len(shape), dom13, list(shape))
+        g13[f"{tag}_values"] = vals
+        g13[f"{tag}_per_dim"] = np.array(ob._error_estimate_per_dim())
+        g13[f"{tag}_coeffs0"] = ChebyshevApproximation._chebyshev_coefficients_1d(vals.reshape(-1)[: shape[0]] if len(shape) == 1 else vals[(slice(None),) + (0,) * (len(shape) - 1)])
+    un = ChebyshevApproximation(F.sin_cos_2d, 2, [[-1, 1], [-1, 1]], [12, 12])
+    g13["unbuilt_str"] = np.array(str(un))
+    big = ChebyshevApproximation(F.sin_sum_nd, 8, [[0, 1]] * 8, [3] * 8)
+    g13["big_str"] = np.array(str(big))
+    tts = ChebyshevTT(F.sin_sum_3d, 3, [[-1, 1]] * 3, [11, 11, 11], max_rank=5)
+    g13["tt_unbuilt_str"] = np.array(str(tts))
+    tts.build(verbose=False, seed=42)
+    g13["tt_built_str"] = np.array(str(tts))
+    g13["tt_error_estimate"] = np.array(tts.error_estimate())
+    save("g13_estimates", **g13)
 
     print(f"done in {time.time() - t0:.1f}s")
 

@@ -427,3 +427,39 @@ def test_integrate_matches_reference(bs5d):
         c.integrate(dims=[5])
     with pytest.raises(NotImplementedError):
         c.integrate(dims=[0], bounds=(90.0, 100.0))
+
+
+# ------------------------------------------------------------------ error estimate / str (device contractions)
+def test_error_estimate_and_str_match_reference():
+    g = golden("g13_estimates")
+    bs = ChebyshevApproximation.from_values(golden("g2_bs5d")["tensor"], 5, F.BS5_DOMAIN, [11] * 5)
+    scale = float(np.max(np.abs(bs.tensor_values)))
+    per_dim = np.array(bs._error_estimate_per_dim())
+    # the reference takes the last DCT coefficient from an FFT, here it is a dot product: both
+    # carry rounding of order eps * max|tensor|, far below the estimates themselves
+    assert np.max(np.abs(per_dim - g["bs_per_dim"])) <= 64 * np.finfo(float).eps * scale
+    assert abs(bs.error_estimate() - float(g["bs_total"])) <= 64 * np.finfo(float).eps * scale
+    assert str(bs) == str(g["bs_str"])
+    for tag in "abcd":
+        vals = g[f"{tag}_values"]
+        ob = ChebyshevApproximation.from_values(vals, vals.ndim, [[-1.0, 2.0]] * vals.ndim, list(vals.shape))
+        assert np.allclose(ob._error_estimate_per_dim(), g[f"{tag}_per_dim"], rtol=0, atol=1e-14), tag
+    with pytest.warns(DeprecationWarning):
+        v = bs.fast_eval([100.0, 100.0, 0.5, 0.2, 0.03], [0, 0, 0, 0, 0])
+    assert v == bs.vectorized_eval([100.0, 100.0, 0.5, 0.2, 0.03], [0, 0, 0, 0, 0])
+
+
+def test_tt_str_matches_reference():
+    from pychebyshev_amd import ChebyshevTT
+    g = golden("g13_estimates")
+    tt = ChebyshevTT(F.sin_sum_3d, 3, [[-1, 1]] * 3, [11, 11, 11], max_rank=5)
+    tt.build(verbose=False, seed=42)
+    ours, ref = str(tt).split("\n"), str(g["tt_built_str"]).split("\n")
+    assert len(ours) == len(ref)
+    for a, b in zip(ours, ref):
+        if a.startswith("  Build:"):          # wall time differs
+            assert a.split("s (")[1] == b.split("s (")[1]
+        elif a.startswith("  Error est:"):    # ~1e-16: rounding-level quantity, compare magnitudes
+            assert float(a.split()[-1]) < 1e-14 and float(b.split()[-1]) < 1e-14
+        else:
+            assert a == b

@@ -267,3 +267,23 @@ def test_shard_bounds_cover_everything_once():
             assert all(lo <= hi for lo, hi in blocks)
     with pytest.raises(ValueError):
         shard_bounds(10, 2, 2)
+
+
+# ------------------------------------------------------------------ str() / coefficients
+def test_str_and_chebyshev_coefficients_match_reference():
+    g = golden("g13_estimates")
+    un = ChebyshevApproximation(F.sin_cos_2d, 2, [[-1, 1], [-1, 1]], [12, 12])
+    assert str(un) == str(g["unbuilt_str"])
+    big = ChebyshevApproximation(F.sin_sum_nd, 8, [[0, 1]] * 8, [3] * 8)
+    assert str(big) == str(g["big_str"])
+    tt = ChebyshevTT(F.sin_sum_3d, 3, [[-1, 1]] * 3, [11, 11, 11], max_rank=5)
+    assert str(tt) == str(g["tt_unbuilt_str"])
+    for tag in "abcd":
+        vals = g[f"{tag}_values"]
+        first = vals if vals.ndim == 1 else vals[(slice(None),) + (0,) * (vals.ndim - 1)]
+        c = ChebyshevApproximation._chebyshev_coefficients_1d(first)
+        assert np.allclose(c, g[f"{tag}_coeffs0"], rtol=0, atol=1e-14)
+        q = ChebyshevApproximation._last_coefficient_vector(len(first))
+        assert abs(q @ first - g[f"{tag}_coeffs0"][-1]) < 1e-14
+    with pytest.raises(RuntimeError, match="build"):
+        un.error_estimate()
