@@ -132,11 +132,14 @@ __device__ __forceinline__ double code_weight(unsigned code, const double *bw_co
 // ---------------------------------------------------------------------------------
 #define PCX_CHUNK_TILES 4
 
-template <int KS, int NT>
+// WIDE: more than four head or tail dimensions (d up to 16): every code has a second word
+// (rowcode_hi / kcode_hi, fields 4..7) and a weight is the product of both words' products.
+template <int KS, int NT, bool WIDE>
 __global__ void __launch_bounds__(256, 2)
 k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             const double *__restrict__ wts, const double *const *__restrict__ frag_tab,
             const unsigned *__restrict__ rowcode, const unsigned *__restrict__ kcode,
+            const unsigned *__restrict__ rowcode_hi, const unsigned *__restrict__ kcode_hi,
             const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
             long ooff, int chunks_per_split, double *__restrict__ partial,
             const int *__restrict__ perm) {
@@ -184,6 +187,11 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         unsigned code = kcode[4 * s + g];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bw + 16 * nt + c, PW);
+        if (WIDE) {
+            unsigned hi = kcode_hi[4 * s + g];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) B[nt][s] *= code_weight(hi, bw + 16 * nt + c, PW);
+        }
     }
 
     // ---- main loop over row tiles; every PCX_CHUNK_TILES tiles the per-lane chunk sum cs
@@ -202,6 +210,11 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             unsigned code = rowcode[16 * t + g + 4 * j];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) w[nt][j] = code_weight(code, bw + 16 * nt + c, PW);
+            if (WIDE) {
+                unsigned hi = rowcode_hi[16 * t + g + 4 * j];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w[nt][j] *= code_weight(hi, bw + 16 * nt + c, PW);
+            }
         }
         pcx_d4 acc[NT];
 #pragma unroll

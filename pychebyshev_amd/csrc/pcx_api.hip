@@ -193,6 +193,8 @@ struct pcx_bary {
     BaryMfmaPlan plan;
     int nt = 2;                      // point tiles per wave in the MFMA kernel
     unsigned *d_rowcode = nullptr, *d_kcode = nullptr;
+    unsigned *d_rowcode_hi = nullptr, *d_kcode_hi = nullptr;   // fields 4..7 (wide plans only)
+    bool wide = false;      // more than four head or tail dimensions
     int lpp = 64;                    // lanes per point in the rows kernel
     bool mfma4_ok = false;           // 4x4x4_4b form available (LDS budget)
     int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b
@@ -222,8 +224,8 @@ static int pick_ks(int K) {
 static bool plan_mfma(const BaryDims &dm, BaryMfmaPlan &best) {
     bool found = false;
     long best_cost = 0;
-    for (int split = std::max(0, dm.d - PCX_CODE_FIELDS); split < dm.d; ++split) {
-        if (split > PCX_CODE_FIELDS) continue;  // head dims must fit one row code
+    for (int split = std::max(0, dm.d - 2 * PCX_CODE_FIELDS); split < dm.d; ++split) {
+        if (split > 2 * PCX_CODE_FIELDS) continue;  // head dims must fit the two words of a row code
         long M = 1, K = 1;
         for (int k = 0; k < split; ++k) M *= dm.n[k];
         for (int k = split; k < dm.d; ++k) K *= dm.n[k];
@@ -263,6 +265,7 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     h->pin.release();
     (void)hipFree(h->d_nodes); (void)hipFree(h->d_wts); (void)hipFree(h->d_diff);
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
+    (void)hipFree(h->d_rowcode_hi); (void)hipFree(h->d_kcode_hi);
     h->s_pts.release(); h->s_out.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
@@ -345,13 +348,16 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->nt = 1;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->mfma_ok = false;
     }
-    h->mfma4_ok = h->mfma_ok && mfma4_lds_bytes(h->dims, h->plan.KS) <= 160 * 1024;
+    h->mfma4_ok = h->mfma_ok && mfma4_lds_bytes(h->dims, h->plan.KS) <= 160 * 1024 &&
+                  h->plan.split <= PCX_CODE_FIELDS && d - h->plan.split <= PCX_CODE_FIELDS;
     if (h->mfma_ok) {
         const BaryMfmaPlan &p = h->plan;
         const unsigned ones = (unsigned)sum_n;  // index of the all-ones table row
         std::vector<unsigned> rowcode((size_t)p.MT * 16), kcode((size_t)p.KS * 4);
+        std::vector<unsigned> rowcode_hi(rowcode.size()), kcode_hi(kcode.size());
+        h->wide = p.split > PCX_CODE_FIELDS || d - p.split > PCX_CODE_FIELDS;
         for (long m = 0; m < (long)p.MT * 16; ++m) {
-            unsigned f[PCX_CODE_FIELDS] = {ones, ones, ones, ones};
+            unsigned f[2 * PCX_CODE_FIELDS] = {ones, ones, ones, ones, ones, ones, ones, ones};
             if (m < p.M) {
                 long rem = m;
                 for (int k = p.split - 1; k >= 0; --k) {
@@ -361,9 +367,10 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
                 }
             }
             rowcode[m] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
+            rowcode_hi[m] = f[4] | (f[5] << 8) | (f[6] << 16) | (f[7] << 24);
         }
         for (long kk = 0; kk < (long)p.KS * 4; ++kk) {
-            unsigned f[PCX_CODE_FIELDS] = {ones, ones, ones, ones};
+            unsigned f[2 * PCX_CODE_FIELDS] = {ones, ones, ones, ones, ones, ones, ones, ones};
             if (kk < p.K) {
                 long rem = kk;
                 for (int k = d - 1; k >= p.split; --k) {
@@ -373,6 +380,13 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
                 }
             }
             kcode[kk] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
+            kcode_hi[kk] = f[4] | (f[5] << 8) | (f[6] << 16) | (f[7] << 24);
+        }
+        if (h->wide) {
+            CREATE_TRY(hipMalloc((void **)&h->d_rowcode_hi, rowcode_hi.size() * sizeof(unsigned)));
+            CREATE_TRY(hipMalloc((void **)&h->d_kcode_hi, kcode_hi.size() * sizeof(unsigned)));
+            CREATE_TRY(hipMemcpy(h->d_rowcode_hi, rowcode_hi.data(), rowcode_hi.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+            CREATE_TRY(hipMemcpy(h->d_kcode_hi, kcode_hi.data(), kcode_hi.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         }
         CREATE_TRY(hipMalloc((void **)&h->d_rowcode, rowcode.size() * sizeof(unsigned)));
         CREATE_TRY(hipMalloc((void **)&h->d_kcode, kcode.size() * sizeof(unsigned)));
@@ -518,13 +532,13 @@ static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **ou
 // batches are split over grid.y (chunks of row tiles) so that a handful of points still
 // uses the whole chip; the per-chunk totals are then added by k_bary_reduce in the fixed
 // chunk order, which makes every result independent of the batch size.
-template <int KS, int NT>
+template <int KS, int NT, bool WIDE>
 static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
                          double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
                          const int *perm) {
     const bool allow_split = split_scratch != nullptr;
     size_t lds = mfma_lds_bytes(h->dims, NT);
-    auto kern = k_bary_mfma<KS, NT>;
+    auto kern = k_bary_mfma<KS, NT, WIDE>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long per_wg = 4L * 16 * NT;
@@ -545,8 +559,8 @@ static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, cons
         partial = (double *)split_scratch->ptr;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit, (unsigned)m), dim3(256), lds, st,
-                       h->dims, h->plan, h->d_nodes, h->d_wts, frag_tab, h->d_rowcode, h->d_kcode, d_pts,
-                       d_out, N, ostride, ooff, cps, partial, perm);
+                       h->dims, h->plan, h->d_nodes, h->d_wts, frag_tab, h->d_rowcode, h->d_kcode,
+                       h->d_rowcode_hi, h->d_kcode_hi, d_pts, d_out, N, ostride, ooff, cps, partial, perm);
     HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
         long cnt = N * m;
@@ -586,12 +600,12 @@ static int launch_mfma4(pcx_bary *h, const double *const *frag_tab, int m, const
     return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d", h->plan.KS);
 }
 
-template <int NT>
+template <int NT, bool WIDE>
 static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
                           double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
                           const int *perm) {
     switch (h->plan.KS) {
-#define CASE_KS(v) case v: return launch_mfma_t<v, NT>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+#define CASE_KS(v) case v: return launch_mfma_t<v, NT, WIDE>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
         CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8)
         CASE_KS(9) CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
         CASE_KS(17) CASE_KS(18) CASE_KS(19) CASE_KS(20) CASE_KS(21) CASE_KS(22) CASE_KS(23) CASE_KS(24)
@@ -634,8 +648,11 @@ static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const doub
         if (!h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
         // two column tiles per wave for throughput; one when the batch cannot fill the chip
         int nt = (N >= 65536) ? h->nt : 1;
-        return nt == 2 ? launch_mfma_nt<2>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm)
-                       : launch_mfma_nt<1>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+        if (h->wide)
+            return nt == 2 ? launch_mfma_nt<2, true>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm)
+                           : launch_mfma_nt<1, true>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+        return nt == 2 ? launch_mfma_nt<2, false>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm)
+                       : launch_mfma_nt<1, false>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
     }
     for (int s = 0; s < m; ++s) {
         int rc = launch_rows(h, *dts[s], d_pts, N, d_out, ostride, ooff + s, st, perm);

@@ -164,7 +164,11 @@ def test_derivative_tensor_kernel_is_bit_identical_to_oracle(bs5d, oracle_mod):
     ((5, 6, 7), [[0, 1], [1, 2], [2, 3]]),
     ((3, 4, 2, 5, 3, 2), [[-1, 1]] * 6),
     ((2, 3, 2, 3, 2, 3, 2, 3), [[0, 1]] * 8),
-    ((2, 2, 2, 2, 2, 2, 2, 2, 2, 3), [[0, 1]] * 10),      # d = 10 > 8: rows kernel only
+    ((2, 2, 2, 2, 2, 2, 2, 2, 2, 3), [[0, 1]] * 10),      # d = 10: wide codes (6 head + 4 tail fields)
+    ((3,) * 10, [[-1, 1]] * 10),                            # 59,049 entries, wide codes
+    ((4,) * 8, [[0, 2]] * 8),                               # 65,536 entries, 5 head + 3 tail dims
+    ((2,) * 16, [[0, 1]] * 16),                             # d = 16: 8 + 8 fields, K = 256 > 128 -> rows kernel
+    ((3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2), [[0, 1]] * 13),   # d = 13: wide, 8-dim tail K = 128... head 5
     ((130, 2), [[0.0, 1.0], [0.0, 1.0]]),                  # last-dim n > 128 with K too large -> split picks head
     ((2, 200), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 200 > 128: rows kernel
 ])
@@ -188,8 +192,10 @@ def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     info = _lib.i32(np.zeros(6))
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
-    if d > 8 or shape == (2, 200):
+    if d == 16 or shape == (2, 200):
         assert info[0] == 1, "expected the rows kernel for this shape"
+    elif d >= 8:
+        assert info[0] == 2, "expected the (wide-code) MFMA kernel for this shape"
 
 
 def test_both_mfma_forms_are_bit_identical(bs5d):
