@@ -209,9 +209,11 @@ struct pcx_bary {
 
 static const int kMaxSpecs = 64;
 
-// every k-step count up to 32 is instantiated: no padding of the folded K axis beyond 4
+// every k-step count up to 32 is instantiated: no padding of the folded K axis beyond 4;
+// 36..64 (one column tile per wave only: the B operands alone are up to 128 VGPRs) let two
+// tail dimensions of 12..16 nodes fold into K
 static const int kKsList[] = {1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22,
-                              23, 24, 25, 26, 27, 28, 29, 30, 31, 32};
+                              23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 36, 40, 44, 48, 52, 56, 60, 64};
 
 static int pick_ks(int K) {
     int need = (K + 3) / 4;
@@ -220,7 +222,9 @@ static int pick_ks(int K) {
     return -1;
 }
 
-// choose the head/tail split minimising the number of MFMAs (MT * KS)
+// choose the head/tail split minimising the estimated time: MT row tiles, each KS MFMAs plus
+// an epilogue (head-weight look-ups and products) worth about 5 MFMAs (measured on 15^4,
+// tools/bary_rate_probe.py); the single-column-tile kernels re-read A twice as often
 static bool plan_mfma(const BaryDims &dm, BaryMfmaPlan &best) {
     bool found = false;
     long best_cost = 0;
@@ -229,11 +233,11 @@ static bool plan_mfma(const BaryDims &dm, BaryMfmaPlan &best) {
         long M = 1, K = 1;
         for (int k = 0; k < split; ++k) M *= dm.n[k];
         for (int k = split; k < dm.d; ++k) K *= dm.n[k];
-        if (K > 128 || M > (1 << 24)) continue;
+        if (K > 256 || M > (1 << 24)) continue;
         int ks = pick_ks((int)K);
         if (ks < 0) continue;
         long mt = (M + 15) / 16;
-        long cost = mt * ks;
+        long cost = mt * (ks + 5) * (ks > 32 ? 23 : 20);
         if (!found || cost < best_cost || (cost == best_cost && K > best.K)) {
             found = true;
             best_cost = cost;
@@ -344,12 +348,12 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     // MFMA plan + row/k codes
     h->mfma_ok = (sum_n <= PCX_MAX_SUM_N) && plan_mfma(h->dims, h->plan);
     if (h->mfma_ok) {
-        h->nt = 2;
+        h->nt = (h->plan.KS > 32) ? 1 : 2;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->nt = 1;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->mfma_ok = false;
     }
     h->mfma4_ok = h->mfma_ok && mfma4_lds_bytes(h->dims, h->plan.KS) <= 160 * 1024 &&
-                  h->plan.split <= PCX_CODE_FIELDS && d - h->plan.split <= PCX_CODE_FIELDS;
+                  h->plan.KS <= 32 && h->plan.split <= PCX_CODE_FIELDS && d - h->plan.split <= PCX_CODE_FIELDS;
     if (h->mfma_ok) {
         const BaryMfmaPlan &p = h->plan;
         const unsigned ones = (unsigned)sum_n;  // index of the all-ones table row
@@ -612,7 +616,14 @@ static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, con
         CASE_KS(25) CASE_KS(26) CASE_KS(27) CASE_KS(28) CASE_KS(29) CASE_KS(30) CASE_KS(31) CASE_KS(32)
 #undef CASE_KS
     }
-    return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d", h->plan.KS);
+    if constexpr (NT == 1) {
+        switch (h->plan.KS) {
+#define CASE_KS(v) case v: return launch_mfma_t<v, 1, WIDE>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+            CASE_KS(36) CASE_KS(40) CASE_KS(44) CASE_KS(48) CASE_KS(52) CASE_KS(56) CASE_KS(60) CASE_KS(64)
+#undef CASE_KS
+        }
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d, NT=%d", h->plan.KS, NT);
 }
 
 static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,

@@ -167,10 +167,13 @@ def test_derivative_tensor_kernel_is_bit_identical_to_oracle(bs5d, oracle_mod):
     ((2, 2, 2, 2, 2, 2, 2, 2, 2, 3), [[0, 1]] * 10),      # d = 10: wide codes (6 head + 4 tail fields)
     ((3,) * 10, [[-1, 1]] * 10),                            # 59,049 entries, wide codes
     ((4,) * 8, [[0, 2]] * 8),                               # 65,536 entries, 5 head + 3 tail dims
-    ((2,) * 16, [[0, 1]] * 16),                             # d = 16: 8 + 8 fields, K = 256 > 128 -> rows kernel
+    ((2,) * 16, [[0, 1]] * 16),                             # d = 16: 8 + 8 fields, K = 256 (64 k-steps)
+    ((14, 13, 15), [[0, 1], [-1, 0], [2, 3]]),              # two tail dims fold into K = 195 (52 k-steps)
+    ((16,) * 4, [[-1, 1]] * 4),                             # K = 256, M = 256
     ((3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2), [[0, 1]] * 13),   # d = 13: wide, 8-dim tail K = 128... head 5
     ((130, 2), [[0.0, 1.0], [0.0, 1.0]]),                  # last-dim n > 128 with K too large -> split picks head
-    ((2, 200), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 200 > 128: rows kernel
+    ((2, 200), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 200: single-column-tile kernel, 52 k-steps
+    ((2, 300), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 300 > 256 and sum_n > 254: rows kernel
 ])
 def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     rng = np.random.default_rng(sum(shape))
@@ -192,10 +195,10 @@ def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     info = _lib.i32(np.zeros(6))
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
-    if d == 16 or shape == (2, 200):
+    if shape == (2, 300):
         assert info[0] == 1, "expected the rows kernel for this shape"
-    elif d >= 8:
-        assert info[0] == 2, "expected the (wide-code) MFMA kernel for this shape"
+    elif d >= 8 or shape in ((2, 200), (14, 13, 15), (16,) * 4):
+        assert info[0] == 2, "expected the MFMA kernel for this shape"
 
 
 def test_both_mfma_forms_are_bit_identical(bs5d):
