@@ -218,6 +218,42 @@ class ChebyshevSpline(DerivativeIdMixin):
             print(f"Build complete in {self._build_time:.3f}s")
 
     @classmethod
+    def from_values(cls, piece_values, num_dimensions: int, domain, n_nodes, knots,
+                    max_derivative_order: int = 2) -> "ChebyshevSpline":
+        """Spline from precomputed value tensors, one per piece in C order over the
+        per-dimension intervals, all of shape ``tuple(n_nodes)`` (reference spline.py:1218-1358).
+        The result has ``function=None`` and is fully built."""
+        if _is_nested(n_nodes):
+            raise NotImplementedError("ChebyshevSpline.from_values() accepts only flat n_nodes "
+                                      "(one int per dim, shared across pieces).")
+        for d in range(num_dimensions):
+            lo, hi = domain[d]
+            if lo >= hi:
+                raise ValueError(f"domain[{d}]: lo={lo} must be strictly less than hi={hi}")
+            for k in knots[d]:
+                if not (lo < k < hi):
+                    raise ValueError(f"Knot {k} for dimension {d} is not strictly "
+                                     f"inside domain [{lo}, {hi}]")
+            if list(knots[d]) != sorted(knots[d]):
+                raise ValueError(f"Knots for dimension {d} must be sorted")
+            if len(knots[d]) != len(set(knots[d])):
+                raise ValueError(f"Knots for dimension {d} contain duplicates")
+        obj = cls(None, num_dimensions, [list(b) for b in domain], n_nodes=list(n_nodes),
+                  knots=[list(k) for k in knots], max_derivative_order=max_derivative_order)
+        if len(piece_values) != len(obj._pieces):
+            raise ValueError(f"Expected {len(obj._pieces)} piece_values, got {len(piece_values)}")
+        want = tuple(n_nodes)
+        for flat, pv in enumerate(piece_values):
+            if np.asarray(pv).shape != want:
+                raise ValueError(f"piece_values[{flat}] has shape {np.asarray(pv).shape}, expected {want}")
+        for flat, multi in enumerate(itertools.product(*[range(n) for n in obj._shape])):
+            obj._pieces[flat] = ChebyshevApproximation.from_values(
+                piece_values[flat], num_dimensions, obj._piece_domain(multi), list(n_nodes),
+                max_derivative_order=max_derivative_order)
+        obj._built = True
+        return obj
+
+    @classmethod
     def from_pieces(cls, pieces: Sequence[ChebyshevApproximation], num_dimensions: int, domain, knots,
                     max_derivative_order: int = 2) -> "ChebyshevSpline":
         """Assemble a spline from already-built pieces in C order over the intervals
@@ -393,12 +429,19 @@ class ChebyshevSpline(DerivativeIdMixin):
             with open(path, "wb") as f:
                 pickle.dump(self, f, protocol=pickle.HIGHEST_PROTOCOL)
         elif format == "binary":
-            raise NotImplementedError(".pcb spline files are not implemented in this build")
+            from . import _binary
+            with open(path, "wb") as f:
+                _binary.write_spline(f, self)
         else:
             raise ValueError(f"format must be 'pickle' or 'binary', got {format!r}")
 
     @classmethod
     def load(cls, path) -> "ChebyshevSpline":
+        """Pickle or ``.pcb`` (detected by the magic bytes; reference spline.py:1064-1108)."""
+        from . import _binary
+        if _binary.detect_format(path) == "binary":
+            with open(path, "rb") as f:
+                return _binary.read_spline(f)
         with open(path, "rb") as f:
             obj = pickle.load(f)  # noqa: S301 - same trust model as the reference
         if not isinstance(obj, cls):

@@ -22,6 +22,7 @@ Sets:
   g9..g11          splines, sliders, slice/integrate (rows f2, f4, f3)
   g12_tt_svd       TT-SVD: from_values on the 5-D BS tensor, build(method="svd") on small cases
   g13_estimates    error_estimate() / per-dimension values, str() of built and unbuilt objects
+  g14_spline_pcb   class-tag-2 .pcb: the reference's spline fixture and a 2-D spline file written by it
 """
 from __future__ import annotations
 
@@ -415,6 +416,25 @@ def main():
     g13["tt_built_str"] = np.array(str(tts))
     g13["tt_error_estimate"] = np.array(tts.error_estimate())
     save("g13_estimates", **g13)
+
+    # ---------------------------------------------------------------- g14 (spline .pcb, row f1/f2)
+    from pychebyshev import ChebyshevSpline
+    g14 = {}
+    fix = ChebyshevSpline.load(os.path.join(args.ref, "tests", "fixtures", "spline_1d_kink.pcb"))
+    x14 = np.random.default_rng(14).uniform(-1, 1, (500, 1))
+    g14["kink_points"] = x14
+    g14["kink_eval"] = fix.eval_batch(x14, [0])
+    g14["kink_d1"] = fix.eval_batch(x14, [1])
+    sp2 = ChebyshevSpline(F.kink_2d, 2, [[-1.0, 2.0], [0.0, 1.0]], [7, 5], [[0.5], [0.25, 0.6]])
+    sp2.build(verbose=False)
+    if not ONLY or "g14" in ONLY:
+        sp2.save(os.path.join(HERE, "spline_2d_ref.pcb"), format="binary")   # written BY the reference
+    rng14 = np.random.default_rng(15)
+    p14 = np.column_stack([rng14.uniform(-1, 2, 400), rng14.uniform(0, 1, 400)])
+    g14["sp2_points"] = p14
+    g14["sp2_eval"] = sp2.eval_batch(p14, [0, 0])
+    g14["sp2_dx"] = sp2.eval_batch(p14, [1, 0])
+    save("g14_spline_pcb", **g14)
 
     print(f"done in {time.time() - t0:.1f}s")
 

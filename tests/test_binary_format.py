@@ -131,3 +131,61 @@ def test_models_loaded_from_pcb_evaluate_like_the_reference(tmp_path):
     assert lib.pcx_bary_create_from_pcb(0, str(bad).encode(), ctypes.byref(h)) == _lib.PCX_ERR_INVALID
     assert b"class tag" in lib.pcx_last_error()
     assert lib.pcx_bary_create_from_pcb(0, b"/nonexistent/x.pcb", ctypes.byref(h)) == _lib.PCX_ERR_INVALID
+
+
+# ------------------------------------------------------------------ splines (class tag 2)
+def test_spline_pcb_round_trip_is_byte_exact_with_the_reference(tmp_path):
+    """Read the file the reference wrote (tests/golden/spline_2d_ref.pcb), write it back:
+    same bytes.  No evaluation, so this runs without a GPU."""
+    from pychebyshev_amd import ChebyshevSpline
+    src = os.path.join(GOLDEN, "spline_2d_ref.pcb")
+    sp = ChebyshevSpline.load(src)
+    assert sp.num_dimensions == 2 and sp.n_nodes == [7, 5] and sp.knots == [[0.5], [0.25, 0.6]]
+    assert sp.num_pieces == 6 and sp.function is None and sp.is_construction_finished()
+    out = tmp_path / "again.pcb"
+    sp.save(out, format="binary")
+    assert out.read_bytes() == open(src, "rb").read()
+    kink = ChebyshevSpline.load(os.path.join(GOLDEN, "spline_1d_kink.pcb"))
+    assert kink.knots == [[0.0]] and kink.n_nodes == [8] and kink.domain == [[-1.0, 1.0]]
+    with pytest.raises(ValueError, match="class_tag"):
+        ChebyshevApproximation.load(src)
+    with pytest.raises(ValueError, match="class_tag"):
+        with open(os.path.join(GOLDEN, "approx_2d_simple.pcb"), "rb") as f:
+            _binary.read_spline(f)
+
+
+def test_spline_pcb_rejects_what_the_format_cannot_hold(tmp_path):
+    from pychebyshev_amd import ChebyshevSpline
+    vals = [np.zeros((3, 2)), np.ones((3, 2))]
+    sp = ChebyshevSpline.from_values(vals, 2, [[0, 1], [0, 1]], [3, 2], [[0.5], []])
+    sp.additional_data = {"x": 1}
+    with pytest.raises(NotImplementedError, match="additional_data"):
+        sp.save(tmp_path / "a.pcb", format="binary")
+    with pytest.raises(ValueError, match="Expected 2 piece_values"):
+        ChebyshevSpline.from_values(vals[:1], 2, [[0, 1], [0, 1]], [3, 2], [[0.5], []])
+    with pytest.raises(ValueError, match="shape"):
+        ChebyshevSpline.from_values([np.zeros((3, 2)), np.zeros((2, 3))], 2, [[0, 1], [0, 1]], [3, 2], [[0.5], []])
+    with pytest.raises(ValueError, match="duplicates"):
+        ChebyshevSpline.from_values(vals * 2, 2, [[0, 1], [0, 1]], [3, 2], [[0.5, 0.5], []])
+    good = open(os.path.join(GOLDEN, "spline_2d_ref.pcb"), "rb").read()
+    bad = tmp_path / "trunc.pcb"
+    bad.write_bytes(good[:-5])
+    with pytest.raises(ValueError, match="EOF"):
+        ChebyshevSpline.load(bad)
+    wrong = bytearray(good)
+    struct.pack_into("<I", wrong, 12 + 4 + 32 + 8 + 8 + 24, 7)      # num_pieces field
+    bad.write_bytes(bytes(wrong))
+    with pytest.raises(ValueError, match="num_pieces"):
+        ChebyshevSpline.load(bad)
+
+
+@pytest.mark.gpu
+def test_spline_pcb_files_evaluate_like_the_reference():
+    from pychebyshev_amd import ChebyshevSpline
+    g = golden("g14_spline_pcb")
+    kink = ChebyshevSpline.load(os.path.join(GOLDEN, "spline_1d_kink.pcb"))
+    assert_parity(kink.eval_batch(g["kink_points"], [0]), g["kink_eval"], 1e-12, "kink value")
+    assert_parity(kink.eval_batch(g["kink_points"], [1]), g["kink_d1"], 1e-12, "kink d/dx", point_tol=1e-10)
+    sp = ChebyshevSpline.load(os.path.join(GOLDEN, "spline_2d_ref.pcb"))
+    assert_parity(sp.eval_batch(g["sp2_points"], [0, 0]), g["sp2_eval"], 1e-12, "2-D spline value")
+    assert_parity(sp.eval_batch(g["sp2_points"], [1, 0]), g["sp2_dx"], 1e-12, "2-D spline d/dx", point_tol=1e-9)
