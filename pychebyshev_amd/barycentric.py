@@ -97,6 +97,55 @@ def fejer1_weights(n: int) -> np.ndarray:
     return desc[::-1].copy()
 
 
+def sub_interval_weights(n: int, t_lo: float, t_hi: float) -> np.ndarray:
+    """Quadrature weights at the n type-I nodes (ascending) for the integral over
+    ``[t_lo, t_hi]`` inside [-1, 1]: the Fejer-1 construction with the moments
+    ``I_k = int_{t_lo}^{t_hi} T_k`` (reference _calculus.py:76-128; Waldvogel 2006,
+    Trefethen ATAP ch. 19 for the antiderivatives of T_k)."""
+    tl, th = np.zeros(n + 1), np.zeros(n + 1)
+    tl[0] = th[0] = 1.0
+    if n >= 1:
+        tl[1], th[1] = t_lo, t_hi
+    for k in range(2, n + 1):
+        tl[k] = 2.0 * t_lo * tl[k - 1] - tl[k - 2]
+        th[k] = 2.0 * t_hi * th[k - 1] - th[k - 2]
+    mom = np.zeros(n)
+    mom[0] = t_hi - t_lo
+    if n > 1:
+        mom[1] = (t_hi ** 2 - t_lo ** 2) / 2.0
+    for k in range(2, n):
+        mom[k] = 0.5 * ((th[k + 1] - tl[k + 1]) / (k + 1) - (th[k - 1] - tl[k - 1]) / (k - 1))
+    j = np.arange(n)[:, None]
+    k = np.arange(1, n)[None, :]
+    desc = (mom[0] + 2.0 * (np.cos(np.pi * k * (2 * j + 1) / (2.0 * n)) @ mom[1:])) / n
+    return desc[::-1].copy()
+
+
+def _integration_bounds(dims, bounds, domain):
+    """One ``(lo, hi)`` or ``None`` (= whole domain) per integrated dimension, validated as the
+    reference does (_calculus.py:131-196): a lone tuple serves a single dimension, bounds may
+    overshoot the domain by 1e-14 at most and are clipped to it."""
+    if bounds is None:
+        return [None] * len(dims)
+    if isinstance(bounds, tuple) and len(bounds) == 2 and not isinstance(bounds[0], (list, tuple)):
+        bounds = [bounds]
+    if len(bounds) != len(dims):
+        raise ValueError(f"bounds length {len(bounds)} != dims length {len(dims)}")
+    out = []
+    for d, bd in zip(dims, bounds):
+        if bd is None:
+            out.append(None)
+            continue
+        lo, hi = bd
+        if lo > hi:
+            raise ValueError(f"bounds lo={lo} > hi={hi} for dim {d}")
+        a, b = domain[d]
+        if lo < a - 1e-14 or hi > b + 1e-14:
+            raise ValueError(f"bounds ({lo}, {hi}) outside domain [{a}, {b}] for dim {d}")
+        out.append((max(lo, a), min(hi, b)))
+    return out
+
+
 def _normalize_n_workers(n_workers):
     """``None`` (serial), ``-1`` (all CPUs) or a positive int (reference _parallel.py:19-33)."""
     if n_workers is None:
@@ -546,12 +595,11 @@ class ChebyshevApproximation(DerivativeIdMixin):
     def integrate(self, dims=None, bounds=None):
         """Integrate over ``dims`` (all by default) with Fejer-1 quadrature at the type-I nodes
         (reference barycentric.py:2160-2275; Waldvogel 2006): each axis is contracted on the
-        device with ``w_j (b - a) / 2``.  Returns a float when no dimension is left, else a
-        lower-dimensional interpolant.  Sub-interval ``bounds`` are not implemented here."""
+        device with ``w_j (b - a) / 2``; ``bounds`` (one ``(lo, hi)`` or ``None`` per entry of
+        ``dims``) restrict a dimension to a sub-interval through the sub-interval moments.
+        Returns a float when no dimension is left, else a lower-dimensional interpolant."""
         if self.tensor_values is None:
             raise RuntimeError("Call build() first")
-        if bounds is not None:
-            raise NotImplementedError("sub-interval integration bounds are outside this build's scope")
         if dims is None:
             dims = list(range(self.num_dimensions))
         elif isinstance(dims, (int, np.integer)):
@@ -560,12 +608,19 @@ class ChebyshevApproximation(DerivativeIdMixin):
         for d in dims:
             if d < 0 or d >= self.num_dimensions:
                 raise ValueError(f"dim {d} out of range [0, {self.num_dimensions - 1}]")
+        per_dim = dict(zip(dims, _integration_bounds(dims, bounds, self.domain)))
         tensor = _lib.f64(self.tensor_values)
         nodes, weights, diffs = list(self.nodes), list(self.weights), list(self.diff_matrices)
         domain, n_nodes = [list(b) for b in self.domain], list(self.n_nodes)
         for d in sorted(dims, reverse=True):
             a, b = domain[d]
-            tensor = self._contract(tensor, d, fejer1_weights(n_nodes[d]) * ((b - a) / 2.0))
+            if per_dim[d] is None:
+                quad = fejer1_weights(n_nodes[d])
+            else:
+                lo, hi = per_dim[d]
+                quad = sub_interval_weights(n_nodes[d], 2.0 * (lo - a) / (b - a) - 1.0,
+                                            2.0 * (hi - a) / (b - a) - 1.0)
+            tensor = self._contract(tensor, d, quad * ((b - a) / 2.0))
             for lst in (nodes, weights, diffs, domain, n_nodes):
                 del lst[d]
         if not n_nodes:

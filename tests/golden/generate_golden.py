@@ -417,6 +417,17 @@ def main():
     g13["tt_error_estimate"] = np.array(tts.error_estimate())
     save("g13_estimates", **g13)
 
+    # ---------------------------------------------------------------- g15 (integrate with bounds, row f3)
+    from pychebyshev._calculus import _compute_sub_interval_weights
+    g15 = {"all": np.array(bs.integrate(bounds=[(85.0, 115.0), (95.0, 100.0), None, (0.2, 0.3), (0.01, 0.08)])),
+           "one": np.array(a2.integrate(dims=0, bounds=(-0.5, 0.25)).integrate())}
+    part15 = bs.integrate(dims=[0, 3], bounds=[(90.0, 110.0), None])
+    g15["part_tensor"] = part15.tensor_values
+    for n_, (tl_, th_) in {5: (-1.0, 1.0), 11: (-0.3, 0.7), 12: (0.0, 0.0), 1: (-0.5, 0.5), 2: (-1.0, 0.2), 33: (-0.99, -0.5)}.items():
+        g15[f"w{n_}"] = _compute_sub_interval_weights(n_, tl_, th_)
+        g15[f"w{n_}_t"] = np.array([tl_, th_])
+    save("g15_integrate_bounds", **g15)
+
     # ---------------------------------------------------------------- g14 (spline .pcb, row f1/f2)
     from pychebyshev import ChebyshevSpline
     g14 = {}

@@ -434,8 +434,26 @@ def test_integrate_matches_reference(bs5d):
     assert one.num_dimensions == 4
     with pytest.raises(ValueError):
         c.integrate(dims=[5])
-    with pytest.raises(NotImplementedError):
-        c.integrate(dims=[0], bounds=(90.0, 100.0))
+
+
+def test_integrate_with_sub_interval_bounds_matches_reference(bs5d):
+    """Sub-interval moments instead of the full-domain ones (reference _calculus.py:76-196)."""
+    c, _ = bs5d
+    g = golden("g15_integrate_bounds")
+    total = c.integrate(bounds=[(85.0, 115.0), (95.0, 100.0), None, (0.2, 0.3), (0.01, 0.08)])
+    assert abs(total - float(g["all"])) <= 1e-12 * abs(float(g["all"]))
+    part = c.integrate(dims=[0, 3], bounds=[(90.0, 110.0), None])
+    assert part.num_dimensions == 3
+    assert np.max(np.abs(part.tensor_values - g["part_tensor"])) <= 1e-13 * np.max(np.abs(g["part_tensor"]))
+    a2 = ChebyshevApproximation.load(os.path.join(GOLDEN, "approx_2d_simple.pcb"))
+    one = a2.integrate(dims=0, bounds=(-0.5, 0.25)).integrate()
+    assert abs(one - float(g["one"])) <= 1e-13 * max(1.0, abs(float(g["one"])))
+    with pytest.raises(ValueError, match="outside domain"):
+        c.integrate(dims=[0], bounds=(70.0, 100.0))
+    with pytest.raises(ValueError, match="lo="):
+        c.integrate(dims=[0], bounds=(100.0, 90.0))
+    with pytest.raises(ValueError, match="length"):
+        c.integrate(dims=[0, 1], bounds=[(90.0, 100.0)])
 
 
 # ------------------------------------------------------------------ error estimate / str (device contractions)

@@ -287,3 +287,13 @@ def test_str_and_chebyshev_coefficients_match_reference():
         assert abs(q @ first - g[f"{tag}_coeffs0"][-1]) < 1e-14
     with pytest.raises(RuntimeError, match="build"):
         un.error_estimate()
+
+
+def test_sub_interval_quadrature_weights_match_reference():
+    from pychebyshev_amd.barycentric import fejer1_weights, sub_interval_weights
+    g = golden("g15_integrate_bounds")
+    for n in (5, 11, 12, 1, 2, 33):
+        tl, th = g[f"w{n}_t"]
+        w = sub_interval_weights(n, float(tl), float(th))
+        assert np.max(np.abs(w - g[f"w{n}"])) < 5e-16 * max(1.0, n / 8), n
+    assert np.max(np.abs(sub_interval_weights(9, -1.0, 1.0) - fejer1_weights(9))) < 1e-15
