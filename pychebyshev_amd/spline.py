@@ -448,6 +448,35 @@ class ChebyshevSpline(DerivativeIdMixin):
             raise TypeError(f"Expected a {cls.__name__} instance, got {type(obj).__name__}")
         return obj
 
+    def error_estimate(self) -> float:
+        """Largest per-piece estimate: a point lies in exactly one piece (reference spline.py:702-733)."""
+        if not self._built:
+            raise RuntimeError("Call build() before error_estimate().")
+        if self._cached_error_estimate is None:
+            self._cached_error_estimate = max(p.error_estimate() for p in self._pieces)
+        return self._cached_error_estimate
+
+    def __str__(self) -> str:
+        """Multi-line summary in the reference's layout (spline.py:2013-2074)."""
+        shown = 6
+        if self.num_dimensions > shown:
+            nodes_txt = "[" + ", ".join(str(n) for n in self.n_nodes[:shown]) + ", ...]"
+            knots_txt = "[" + ", ".join(str(k) for k in self.knots[:shown]) + ", ...]"
+            dom_txt = " x ".join(f"[{lo}, {hi}]" for lo, hi in self.domain[:shown]) + " x ..."
+        else:
+            nodes_txt, knots_txt = str(self.n_nodes), str(self.knots)
+            dom_txt = " x ".join(f"[{lo}, {hi}]" for lo, hi in self.domain)
+        out = [f"ChebyshevSpline ({self.num_dimensions}D, {'built' if self._built else 'not built'})",
+               f"  Nodes:       {nodes_txt} per piece",
+               f"  Knots:       {knots_txt}",
+               f"  Pieces:      {self.num_pieces} ({' x '.join(str(n) for n in self._shape)})"]
+        if self._built:
+            out.append(f"  Build:       {self._build_time:.3f}s ({self.total_build_evals:,} function evals)")
+        out.append(f"  Domain:      {dom_txt}")
+        if self._built:
+            out.append(f"  Error est:   {self.error_estimate():.2e}")
+        return "\n".join(out)
+
     def __repr__(self) -> str:
         return (f"ChebyshevSpline(dims={self.num_dimensions}, pieces={self.num_pieces}, "
                 f"shape={self._shape}, built={self._built})")

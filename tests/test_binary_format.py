@@ -186,6 +186,12 @@ def test_spline_pcb_files_evaluate_like_the_reference():
     kink = ChebyshevSpline.load(os.path.join(GOLDEN, "spline_1d_kink.pcb"))
     assert_parity(kink.eval_batch(g["kink_points"], [0]), g["kink_eval"], 1e-12, "kink value")
     assert_parity(kink.eval_batch(g["kink_points"], [1]), g["kink_d1"], 1e-12, "kink d/dx", point_tol=1e-10)
+    text = str(kink).split("\n")                       # the reference's str() of this fixture
+    assert text[:-1] == ["ChebyshevSpline (1D, built)", "  Nodes:       [8] per piece", "  Knots:       [[0.0]]",
+                         "  Pieces:      2 (2)", "  Build:       0.000s (0 function evals)",
+                         "  Domain:      [-1.0, 1.0]"]
+    # |x| is linear on both pieces: the reference prints 0.00e+00, a dot product leaves rounding
+    assert text[-1].startswith("  Error est:   ") and float(text[-1].split()[-1]) < 1e-14
     sp = ChebyshevSpline.load(os.path.join(GOLDEN, "spline_2d_ref.pcb"))
     assert_parity(sp.eval_batch(g["sp2_points"], [0, 0]), g["sp2_eval"], 1e-12, "2-D spline value")
     assert_parity(sp.eval_batch(g["sp2_points"], [1, 0]), g["sp2_dx"], 1e-12, "2-D spline d/dx", point_tol=1e-9)
