@@ -337,8 +337,45 @@ class ChebyshevApproximation(DerivativeIdMixin):
             raise RuntimeError("Cannot build: no function assigned. "
                                "This object was created via from_values() or load().")
         if any(n is None for n in self._original_n_nodes):
-            raise NotImplementedError("error_threshold auto-N builds are outside this build's "
-                                      "hot-path scope; pass explicit n_nodes")
+            self._build_with_threshold(verbose)
+        else:
+            self._build_fixed_grid(verbose)
+
+    def _build_with_threshold(self, verbose: bool | int = True) -> None:
+        """Auto-N (reference barycentric.py:567-645): unresolved dimensions start at 3 nodes; after
+        every fixed-grid build the dimension with the largest last-coefficient magnitude (a
+        device contraction per dimension) is doubled, capped at ``max_n``, until the summed
+        estimate is within ``error_threshold``.  Counters accumulate over the iterations."""
+        sizes = [3 if n is None else n for n in self._original_n_nodes]
+        free = [k for k, n in enumerate(self._original_n_nodes) if n is None]
+        evals, seconds = 0, 0.0
+        while True:
+            self.n_nodes = list(sizes)
+            self._cached_error_estimate = None
+            self._generate_nodes()
+            self._build_fixed_grid(verbose)
+            evals += self.n_evaluations
+            seconds += self.build_time
+            per_dim = self._error_estimate_per_dim()
+            err = float(sum(per_dim))
+            self._cached_error_estimate = err
+            if verbose:
+                print(f"[auto-N] n_nodes={sizes}, error={err:.3e}")
+            if err <= self.error_threshold:
+                break
+            growable = [k for k in free if sizes[k] < self.max_n]
+            if not growable:
+                warnings.warn(f"max_n={self.max_n} reached on all auto dims before "
+                              f"error_threshold={self.error_threshold:.2e} satisfied (last error={err:.3e}). "
+                              f"Increase max_n or relax error_threshold.", RuntimeWarning, stacklevel=3)
+                break
+            worst = min(growable, key=lambda k: (-per_dim[k], k))     # ties -> lowest index
+            sizes[worst] = min(2 * sizes[worst], self.max_n)
+        self.n_evaluations = evals
+        self.build_time = seconds
+
+    def _build_fixed_grid(self, verbose: bool | int = True) -> None:
+        """Tensor fill on the resolved grid (reference :647-715)."""
         total = int(np.prod(self.n_nodes))
         if verbose:
             print(f"Building {self.num_dimensions}D Chebyshev approximation ({total:,} evaluations)...")

@@ -22,6 +22,8 @@ Sets:
   g9..g11          splines, sliders, slice/integrate (rows f2, f4, f3)
   g12_tt_svd       TT-SVD: from_values on the 5-D BS tensor, build(method="svd") on small cases
   g13_estimates    error_estimate() / per-dimension values, str() of built and unbuilt objects
+  g15_integrate_bounds  integrate() with sub-interval bounds, sub-interval quadrature weights
+  g16_auto_n       error_threshold builds: final n_nodes, evaluation counts, estimates, values
   g14_spline_pcb   class-tag-2 .pcb: the reference's spline fixture and a 2-D spline file written by it
 """
 from __future__ import annotations
@@ -427,6 +429,29 @@ def main():
         g15[f"w{n_}"] = _compute_sub_interval_weights(n_, tl_, th_)
         g15[f"w{n_}_t"] = np.array([tl_, th_])
     save("g15_integrate_bounds", **g15)
+
+    # ---------------------------------------------------------------- g16 (auto-N builds)
+    import warnings as _w
+    g16 = {}
+    cases16 = {
+        "a": dict(f=F.sin_cos_2d, d=2, dom=[[-1, 1], [-1, 1]], n=None, thr=1e-8, max_n=64),
+        "b": dict(f=F.exp_mix_3d, d=3, dom=[[-1, 1], [0, 2], [-2, 1]], n=[None, 14, None], thr=1e-7, max_n=64),
+        "c": dict(f=F.bs_3d, d=3, dom=[[80, 120], [0.25, 1.0], [0.15, 0.35]], n=None, thr=1e-12, max_n=12),
+    }
+    for tag, c in cases16.items():
+        ob = ChebyshevApproximation(c["f"], c["d"], c["dom"], c["n"], error_threshold=c["thr"], max_n=c["max_n"])
+        with _w.catch_warnings(record=True) as rec:
+            _w.simplefilter("always")
+            ob.build(verbose=False)
+        g16[f"{tag}_n_nodes"] = np.array(ob.n_nodes)
+        g16[f"{tag}_evals"] = np.array(ob.n_evaluations)
+        g16[f"{tag}_err"] = np.array(ob.error_estimate())
+        g16[f"{tag}_warned"] = np.array(len([r for r in rec if issubclass(r.category, RuntimeWarning)]))
+        rng16 = np.random.default_rng(16)
+        pts16 = np.column_stack([rng16.uniform(lo, hi, 200) for lo, hi in c["dom"]])
+        g16[f"{tag}_points"] = pts16
+        g16[f"{tag}_eval"] = ob.vectorized_eval_batch(pts16, [0] * c["d"])
+    save("g16_auto_n", **g16)
 
     # ---------------------------------------------------------------- g14 (spline .pcb, row f1/f2)
     from pychebyshev import ChebyshevSpline

@@ -490,3 +490,29 @@ def test_tt_str_matches_reference():
             assert float(a.split()[-1]) < 1e-14 and float(b.split()[-1]) < 1e-14
         else:
             assert a == b
+
+
+# ------------------------------------------------------------------ auto-N (error_threshold) builds
+@pytest.mark.parametrize("tag,f,d,dom,n,thr,max_n", [
+    ("a", F.sin_cos_2d, 2, [[-1, 1], [-1, 1]], None, 1e-8, 64),
+    ("b", F.exp_mix_3d, 3, [[-1, 1], [0, 2], [-2, 1]], [None, 14, None], 1e-7, 64),   # decisions well above rounding
+    ("c", F.bs_3d, 3, [[80, 120], [0.25, 1.0], [0.15, 0.35]], None, 1e-12, 12),
+])
+def test_error_threshold_build_follows_the_reference(tag, f, d, dom, n, thr, max_n, capsys):
+    """The doubling loop (reference barycentric.py:567-645) driven by the device-side error
+    estimate: same final grids, evaluation counts, warnings and values."""
+    import warnings
+    g = golden("g16_auto_n")
+    ob = ChebyshevApproximation(f, d, dom, n, error_threshold=thr, max_n=max_n)
+    assert "auto" in str(ob)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        ob.build(verbose=(tag == "a"))
+    assert ob.n_nodes == list(g[f"{tag}_n_nodes"]) and ob.n_evaluations == int(g[f"{tag}_evals"])
+    assert len([r for r in rec if issubclass(r.category, RuntimeWarning)]) == int(g[f"{tag}_warned"])
+    scale = float(np.max(np.abs(ob.tensor_values)))
+    assert abs(ob.error_estimate() - float(g[f"{tag}_err"])) <= 256 * np.finfo(float).eps * scale
+    assert_parity(ob.vectorized_eval_batch(g[f"{tag}_points"], [0] * d), g[f"{tag}_eval"], 1e-12, f"auto-N {tag}")
+    if tag == "a":
+        out = capsys.readouterr().out
+        assert "[auto-N] n_nodes=[3, 3], error=" in out and "[auto-N] n_nodes=[3, 6], error=" in out
