@@ -16,8 +16,9 @@ CPU fallback -- if the library or a device is missing the call raises.  Grid met
 as the reference builds it, and copied to the device when the first evaluation happens.
 
 ``special_points`` with knots dispatch to :class:`pychebyshev_amd.spline.ChebyshevSpline` as in
-the reference.  Out of scope in this tier (raise ``NotImplementedError``): error-threshold
-auto-N, algebra/calculus/extrude/slice.
+the reference.  ``error_threshold`` (auto-N) builds, ``error_estimate``, ``slice`` and
+``integrate`` run their tensor contractions on the device.  Not provided: algebra, roots /
+optimisation, extrude, Sobol indices, plotting.
 """
 from __future__ import annotations
 

@@ -14,8 +14,9 @@ piece's ``vectorized_eval_batch``.  Here routing, bucketing and the per-piece ba
 launches all run on the device (``pcx_spline_eval_batch``: ``k_spline_piece_id`` ->
 ``k_spline_scatter`` -> one ``k_bary_mfma`` launch per non-empty piece on its bucket).
 
-Out of scope in this tier (raise ``NotImplementedError``): auto-N pieces (``error_threshold``),
-``.pcb`` spline files, algebra, calculus, extrude/slice, auto_knots.
+Auto-N pieces (``error_threshold``) build through the pieces' own doubling loop; ``.pcb`` files
+(class tag 2) are read and written byte-compatibly.  Not provided: algebra, calculus,
+extrude/slice, auto_knots.
 """
 from __future__ import annotations
 
