@@ -24,6 +24,7 @@ Sets:
   g13_estimates    error_estimate() / per-dimension values, str() of built and unbuilt objects
   g15_integrate_bounds  integrate() with sub-interval bounds, sub-interval quadrature weights
   g16_auto_n       error_threshold builds: final n_nodes, evaluation counts, estimates, values
+  g17_c_example    value + first partials of the 5-D .pcb fixture at one point (examples/pcb_eval.c)
   g14_spline_pcb   class-tag-2 .pcb: the reference's spline fixture and a 2-D spline file written by it
 """
 from __future__ import annotations
@@ -452,6 +453,12 @@ def main():
         g16[f"{tag}_points"] = pts16
         g16[f"{tag}_eval"] = ob.vectorized_eval_batch(pts16, [0] * c["d"])
     save("g16_auto_n", **g16)
+
+    # ---------------------------------------------------------------- g17 (C ABI example)
+    fx = ChebyshevApproximation.load(os.path.join(HERE, "approx_5d_bs.pcb"))
+    pt17 = [0.1, -0.2, 0.3, 0.4, -0.5]
+    sp17 = [[0] * 5] + [[1 if j == k else 0 for j in range(5)] for k in range(5)]
+    save("g17_c_example", point=np.array(pt17), out=np.array(fx.vectorized_eval_multi(pt17, sp17)))
 
     # ---------------------------------------------------------------- g14 (spline .pcb, row f1/f2)
     from pychebyshev import ChebyshevSpline
