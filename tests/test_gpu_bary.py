@@ -516,3 +516,31 @@ def test_error_threshold_build_follows_the_reference(tag, f, d, dom, n, thr, max
     if tag == "a":
         out = capsys.readouterr().out
         assert "[auto-N] n_nodes=[3, 3], error=" in out and "[auto-N] n_nodes=[3, 6], error=" in out
+
+
+# ------------------------------------------------------------------ seeded fuzz over shapes
+def test_fuzz_random_tensor_shapes_against_oracle(oracle_mod):
+    """40 seeded random shapes (d 1..10, n 1..13): narrow and wide row codes, every k-step
+    count the planner picks, derivative specs, batch sizes around the tile boundaries."""
+    rng = np.random.default_rng(20260102)
+    for case in range(40):
+        d = int(rng.integers(1, 11))
+        cap = 13 if d <= 4 else (6 if d <= 6 else 3)
+        shape = tuple(int(rng.integers(1, cap + 1)) for _ in range(d))
+        dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-5, 5, d), rng.uniform(0.1, 10, d))]
+        T = rng.standard_normal(shape)
+        c = ChebyshevApproximation.from_values(T, d, dom, list(shape))
+        npts = int(rng.choice([1, 31, 32, 33, 127, 128, 129, 500]))
+        pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+        if npts > 3:
+            pts[0, 0] = c.nodes[0][0]                       # exact-node rows
+            pts[1, d - 1] = c.nodes[d - 1][-1]
+        om = _oracle_model(oracle_mod, c)
+        spec = [0] * d
+        if case % 2 and max(shape) > 2:
+            k = int(np.argmax(shape))
+            spec[k] = int(rng.integers(1, 3))
+        ref = oracle_mod.bary_eval_batch(om, pts, spec)
+        got = c.vectorized_eval_batch(pts, spec)
+        scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(T))))
+        assert np.max(np.abs(got - ref)) <= 1e-11 * scale, (case, shape, spec, npts)

@@ -353,3 +353,26 @@ def test_from_values_validation():
     assert tt.eval([0.3, 0.4]) == 0.0
     one = ChebyshevTT.from_values(np.arange(5.0), 1, [[0, 1]], [5])                # 1-D: single core
     assert one.tt_ranks == [1, 1]
+
+
+# ------------------------------------------------------------------ seeded fuzz over shapes
+def test_fuzz_random_tt_models_against_oracle(oracle_mod):
+    """40 seeded random models: d 1..12, ranks 1..20, n 1..20, random domains and dim_order,
+    batch sizes around the tile boundaries -- every kernel class and the padding paths."""
+    rng = np.random.default_rng(20260101)
+    for case in range(40):
+        d = int(rng.integers(1, 13))
+        rmax = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 12, 13, 16, 20]))
+        ranks = [1] + [int(rng.integers(1, rmax + 1)) for _ in range(d - 1)] + [1]
+        n = [int(rng.integers(1, 21)) for _ in range(d)]
+        cores = [rng.standard_normal((ranks[k], n[k], ranks[k + 1])) / np.sqrt(ranks[k] * n[k]) for k in range(d)]
+        dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-5, 5, d), rng.uniform(0.1, 10, d))]
+        order = [int(v) for v in rng.permutation(d)] if case % 3 == 0 else None
+        tt = ChebyshevTT.from_coeff_cores(cores, dom, dim_order=order)
+        npts = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 255, 256, 257, 1000]))
+        user_dom = dom if order is None else [dom[order.index(j)] for j in range(d)]
+        pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in user_dom])
+        ref = oracle_mod.tt_eval_batch(cores, dom, pts, dim_order=order)
+        got = tt.eval_batch(pts)
+        scale = max(float(np.max(np.abs(ref))), 1e-300)
+        assert np.max(np.abs(got - ref)) <= 2e-12 * scale, (case, d, ranks, n, order, npts)
