@@ -147,6 +147,8 @@ struct Scratch {
 
 // Host-pointer batches are processed in chunks so the staging buffers stay bounded.
 static const int64_t kChunkPoints = 1 << 23;
+// ... and, from two such pieces on, in 256 Ki-point pieces alternating between two streams
+static const int64_t kPipeChunkPoints = 1 << 18;
 
 // Small host-pointer batches skip the H2D/D2H copies: the points are memcpy'd into a pinned,
 // device-mapped buffer the kernel reads directly over PCIe, and the results land in a second
@@ -201,6 +203,8 @@ struct pcx_bary {
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
     Scratch s_pts, s_out;
+    hipStream_t stream2 = nullptr;   // second staging slot of the host-pointer pipeline (lazy)
+    Scratch s_pts2, s_out2;
     double **d_tab = nullptr;        // frag table for multi-spec launches (kMaxSpecs entries)
     std::vector<double *> tab_host;  // what d_tab currently holds
     Scratch s_partial;               // per-chunk totals of split launches
@@ -271,6 +275,8 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
     (void)hipFree(h->d_rowcode_hi); (void)hipFree(h->d_kcode_hi);
     h->s_pts.release(); h->s_out.release();
+    h->s_pts2.release(); h->s_out2.release();
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PCX_OK;
@@ -722,19 +728,52 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         memcpy(out, h->pin.out, (size_t)N * m * sizeof(double));
         return PCX_OK;
     }
-    for (int64_t start = 0; start < N; start += kChunkPoints) {
-        long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
-        int rc = h->s_pts.reserve((size_t)cnt * d * sizeof(double));
+    // Two staging slots on two streams: the H2D copy of chunk i+1 and the D2H copy of chunk i-1
+    // overlap the kernel of chunk i.  A slot is reused only after its stream has drained.
+    const int64_t chunk = (N >= 2 * kPipeChunkPoints) ? kPipeChunkPoints : kChunkPoints;
+    if (chunk == kPipeChunkPoints && !h->stream2)
+        HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    // Copies from/to pageable memory block the host until their stream reaches them, so the
+    // result copy of chunk i-1 is issued only after chunk i's upload and launch are queued.
+    int slot = 0;
+    int64_t prev_start = -1;
+    long prev_cnt = 0;
+    auto download = [&](int sl, int64_t start, long cnt) -> int {
+        const bool second = (chunk == kPipeChunkPoints) && sl == 1;
+        HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, (second ? h->s_out2 : h->s_out).ptr,
+                               (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
+        return PCX_OK;
+    };
+    for (int64_t start = 0; start < N; start += chunk, slot ^= 1) {
+        long cnt = (long)std::min<int64_t>(chunk, N - start);
+        const bool second = (chunk == kPipeChunkPoints) && slot == 1;
+        hipStream_t st = second ? h->stream2 : h->stream;
+        Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
+        int rc = sp.reserve((size_t)cnt * d * sizeof(double));
         if (rc) return rc;
-        rc = h->s_out.reserve((size_t)cnt * m * sizeof(double));
+        rc = so.reserve((size_t)cnt * m * sizeof(double));
         if (rc) return rc;
-        double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
-        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        rc = bary_launch(h, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, h->stream, &h->s_partial);
+        double *dp = (double *)sp.ptr, *dout = (double *)so.ptr;
+        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
+        rc = bary_launch(h, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
+        if (chunk != kPipeChunkPoints) {          // single slot: drain before its buffers are reused
+            if ((rc = download(slot, start, cnt))) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            prev_start = -1;
+            slot ^= 1;                             // stay on slot 0
+            continue;
+        }
+        prev_start = start;
+        prev_cnt = cnt;
     }
+    if (prev_start >= 0) {
+        int rc = download(slot ^ 1, prev_start, prev_cnt);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
     return PCX_OK;
 }
 
