@@ -23,9 +23,9 @@ __device__ __forceinline__ double code_weight(unsigned code, const double *bw_co
 // 16 = three-field codes (no read of the all-ones row), 32 = epilogue deferred into the next
 // half's MFMA stream (weights read at k-step 1, used at k-step 8), 64 = row codes fetched one
 // tile ahead, 128 = staging as a straight 16-byte copy (image pre-packed in global memory)
-template <int F, int WAVES>
-__global__ void __launch_bounds__(64 * WAVES, 2) kf(const double *src, const unsigned *codes, double *out, int tiles) {
-    constexpr int THREADS = 64 * WAVES, SLAB = KS * 64, CPT = (SLAB + THREADS - 1) / THREADS, PW = 32;
+template <int F, int WAVES, int NTP, int MINB>
+__global__ void __launch_bounds__(64 * WAVES, MINB) kf(const double *src, const unsigned *codes, double *out, int tiles) {
+    constexpr int NT = NTP; constexpr int THREADS = 64 * WAVES, SLAB = KS * 64, CPT = (SLAB + THREADS - 1) / THREADS, PW = 32;
     constexpr int CPT2 = (SLAB / 2 + THREADS - 1) / THREADS;
     constexpr int NF = (F & 16) ? 3 : 4;
     extern __shared__ double lds[];
@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64 * WAVES, 2) kf(const double *src, const uns
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int s = 0; s < KS; ++s) B[nt][s] = 1.0 + 1e-3 * (lane + s + nt);
-    double cs[NT] = {0.0, 0.0};
+    double cs[NT] = {};
     double stage[CPT];
     d2_t stage2[CPT2];
 #pragma unroll
@@ -148,10 +148,10 @@ __global__ void __launch_bounds__(64 * WAVES, 2) kf(const double *src, const uns
             cs[nt] = __builtin_fma(pacc[1][nt], wprod(w1), cs[nt]);
         }
     }
-    out[(size_t)blockIdx.x * THREADS + threadIdx.x] = cs[0] + cs[1];
+    out[(size_t)blockIdx.x * THREADS + threadIdx.x] = cs[0] + cs[NT - 1];
 }
 
-template <int F, int WAVES>
+template <int F, int WAVES, int NTP = 2, int MINB = 2>
 void runf(const double *src, const unsigned *codes) {
     for (int per_cu : {1, 2}) {
         const int blocks = 256 * per_cu;
@@ -160,15 +160,15 @@ void runf(const double *src, const unsigned *codes) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         const int tiles = 84 * 4;
         const size_t lds = ((size_t)2 * KS * 64 + WAVES * 34 * 32) * 8;
-        hipFuncSetAttribute((const void *)kf<F, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((kf<F, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, 0, src, codes, out, 8); hipDeviceSynchronize();
+        hipFuncSetAttribute((const void *)kf<F, WAVES, NTP, MINB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((kf<F, WAVES, NTP, MINB>), dim3(blocks), dim3(64 * WAVES), lds, 0, src, codes, out, 8); hipDeviceSynchronize();
         float best = 1e30f;
         for (int r = 0; r < 5; ++r) {
-            hipEventRecord(e0); hipLaunchKernelGGL((kf<F, WAVES>), dim3(blocks), dim3(64 * WAVES), lds, 0, src, codes, out, tiles); hipEventRecord(e1);
+            hipEventRecord(e0); hipLaunchKernelGGL((kf<F, WAVES, NTP, MINB>), dim3(blocks), dim3(64 * WAVES), lds, 0, src, codes, out, tiles); hipEventRecord(e1);
             hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (ms < best) best = ms;
         }
-        double flop = (double)blocks * WAVES * tiles * 4 * KS * NT * 512.0;
-        printf("F=%3d  %d waves/WG x %d WG/CU: %.3f ms  %.2f TF (MFMA-executed)\n", F, WAVES, per_cu, best, flop / best / 1e9);
+        double flop = (double)blocks * WAVES * tiles * 4 * KS * NTP * 512.0;
+        printf("NT=%d F=%3d  %d waves/WG x %d WG/CU: %.3f ms  %.2f TF (MFMA-executed)\n", NTP, F, WAVES, per_cu, best, flop / best / 1e9);
         hipFree(out);
     }
 }
@@ -271,10 +271,10 @@ int main(int argc, char **) {
     for (int i = 0; i < 84 * 16; ++i) hc[i] = (unsigned)(i % 11) | ((11 + (i / 11) % 11) << 8) | ((22 + (i / 121) % 11) << 16) | (33u << 24);
     hipMalloc(&codes, sizeof(hc)); hipMemcpy(codes, hc, sizeof(hc), hipMemcpyHostToDevice);
     if (argc > 1) { run<0, 4>(src); run<0, 8>(src); run<1, 4>(src); run<2, 4>(src); run<2, 8>(src); run<4, 4>(src); }
-    runf<255, 4>(src, codes);
-    runf<255 & ~(4 | 128), 4>(src, codes);          // no staging
-    runf<255 & ~(8 | 16 | 32), 4>(src, codes);      // no epilogue weights
-    runf<255 & ~2, 4>(src, codes);                  // no barrier
-    runf<255 & ~(1 | 64), 4>(src, codes);           // no code loads
+    runf<255, 8>(src, codes);
+    runf<255, 8, 1, 2>(src, codes);      // NT = 1: 8 waves/WG x {1,2} WG/CU
+    runf<255, 16, 1, 1>(src, codes);     // 16 waves/WG
+    runf<255, 12, 1, 1>(src, codes);
+    runf<0, 16, 1, 1>(src, codes);       // bare loop, NT = 1
     return 0;
 }
