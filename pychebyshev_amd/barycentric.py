@@ -35,6 +35,7 @@ from numpy.polynomial.chebyshev import chebpts1
 
 from . import _lib
 from ._derivative_ids import DerivativeIdMixin
+from ._ergonomics import ErgonomicsMixin
 from ._version import __version__
 
 __all__ = [
@@ -215,7 +216,7 @@ class _DeviceModel:
             pass
 
 
-class ChebyshevApproximation(DerivativeIdMixin):
+class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
     """Multi-dimensional Chebyshev interpolant evaluated on the GPU.
 
     Parameters mirror the reference (barycentric.py:341-355).  ``function(point, data)``
@@ -510,26 +511,15 @@ class ChebyshevApproximation(DerivativeIdMixin):
     def is_construction_finished(self) -> bool:
         return self.tensor_values is not None
 
-    def get_constructor_type(self) -> str:
-        return type(self).__name__
-
     def get_used_ns(self) -> list:
         return list(self.n_nodes)
 
-    def set_descriptor(self, descriptor: str) -> None:
-        if not isinstance(descriptor, str):
-            raise TypeError(f"descriptor must be str, got {type(descriptor).__name__}")
-        self.descriptor = descriptor
+    def get_error_threshold(self):
+        """The construction-time target (``None`` for a fixed grid), not the achieved estimate."""
+        return self.error_threshold
 
-    def get_descriptor(self) -> str:
-        return self.descriptor
-
-    def get_max_derivative_order(self) -> int:
-        return self.max_derivative_order
-
-    @staticmethod
-    def is_dimensionality_allowed(num_dimensions: int) -> bool:
-        return isinstance(num_dimensions, int) and num_dimensions >= 1
+    def get_num_evaluation_points(self) -> int:
+        return int(np.prod(self.n_nodes))
 
     def get_special_points(self):
         return self.special_points

@@ -25,12 +25,13 @@ import numpy as np
 
 from ._version import __version__
 from ._derivative_ids import DerivativeIdMixin
+from ._ergonomics import ErgonomicsMixin
 from .barycentric import ChebyshevApproximation
 
 __all__ = ["ChebyshevSlider"]
 
 
-class ChebyshevSlider(DerivativeIdMixin):
+class ChebyshevSlider(ErgonomicsMixin, DerivativeIdMixin):
     """Sum of low-dimensional slides around ``pivot_point`` (signature: reference slider.py:80-90)."""
 
     def __init__(self, function: Callable, num_dimensions: int,
@@ -157,11 +158,31 @@ class ChebyshevSlider(DerivativeIdMixin):
     def is_construction_finished(self) -> bool:
         return self._built
 
-    def get_constructor_type(self) -> str:
-        return type(self).__name__
-
     def get_used_ns(self) -> list:
         return list(self.n_nodes)
+
+    def get_num_evaluation_points(self) -> int:
+        return int(self.total_build_evals)
+
+    def get_evaluation_points(self) -> np.ndarray:
+        """Every slide's grid embedded at the pivot in the other dimensions, slide after slide
+        (reference slider.py:479-500)."""
+        pivot = np.array(self.pivot_point, dtype=np.float64)
+        rows = []
+        for slide, group in zip(self.slides, self.partition):
+            grid = slide.get_evaluation_points()
+            full = np.tile(pivot, (len(grid), 1))
+            full[:, list(group)] = grid
+            rows.append(full)
+        return np.concatenate(rows, axis=0)
+
+    def error_estimate(self) -> float:
+        """Sum of the slides' estimates: every slide contributes at every point (reference :343-350)."""
+        if not self._built:
+            raise RuntimeError("Call build() before error_estimate().")
+        if self._cached_error_estimate is None:
+            self._cached_error_estimate = sum(s.error_estimate() for s in self.slides)
+        return self._cached_error_estimate
 
     def __getstate__(self) -> dict:
         state = self.__dict__.copy()

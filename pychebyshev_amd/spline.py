@@ -31,6 +31,7 @@ import numpy as np
 
 from . import _lib
 from ._derivative_ids import DerivativeIdMixin
+from ._ergonomics import ErgonomicsMixin
 from ._version import __version__
 from .barycentric import ChebyshevApproximation
 
@@ -73,7 +74,7 @@ class _DeviceSpline:
             pass
 
 
-class ChebyshevSpline(DerivativeIdMixin):
+class ChebyshevSpline(ErgonomicsMixin, DerivativeIdMixin):
     """Piecewise Chebyshev interpolation with user-specified knots (signature: reference
     spline.py:106-123)."""
 
@@ -218,15 +219,9 @@ class ChebyshevSpline(DerivativeIdMixin):
         if verbose:
             print(f"Build complete in {self._build_time:.3f}s")
 
-    @classmethod
-    def from_values(cls, piece_values, num_dimensions: int, domain, n_nodes, knots,
-                    max_derivative_order: int = 2) -> "ChebyshevSpline":
-        """Spline from precomputed value tensors, one per piece in C order over the
-        per-dimension intervals, all of shape ``tuple(n_nodes)`` (reference spline.py:1218-1358).
-        The result has ``function=None`` and is fully built."""
-        if _is_nested(n_nodes):
-            raise NotImplementedError("ChebyshevSpline.from_values() accepts only flat n_nodes "
-                                      "(one int per dim, shared across pieces).")
+    @staticmethod
+    def _validated_intervals(num_dimensions: int, domain, knots):
+        """Per-dimension sub-intervals after the checks ``nodes`` and ``from_values`` share."""
         for d in range(num_dimensions):
             lo, hi = domain[d]
             if lo >= hi:
@@ -239,6 +234,39 @@ class ChebyshevSpline(DerivativeIdMixin):
                 raise ValueError(f"Knots for dimension {d} must be sorted")
             if len(knots[d]) != len(set(knots[d])):
                 raise ValueError(f"Knots for dimension {d} contain duplicates")
+        out = []
+        for d in range(num_dimensions):
+            edges = [domain[d][0]] + list(knots[d]) + [domain[d][1]]
+            out.append([(edges[i], edges[i + 1]) for i in range(len(edges) - 1)])
+        return out
+
+    @staticmethod
+    def nodes(num_dimensions: int, domain, n_nodes, knots) -> dict:
+        """Where ``from_values`` expects its samples: one grid per piece, pieces in C order over the
+        per-dimension intervals (reference spline.py:1105-1216)."""
+        if _is_nested(n_nodes):
+            raise NotImplementedError("ChebyshevSpline.nodes() accepts only flat n_nodes "
+                                      "(one int per dim, shared across pieces).")
+        intervals = ChebyshevSpline._validated_intervals(num_dimensions, domain, knots)
+        shape = tuple(len(iv) for iv in intervals)
+        pieces = []
+        for multi in itertools.product(*[range(n) for n in shape]):
+            sub = [intervals[d][multi[d]] for d in range(num_dimensions)]
+            info = ChebyshevApproximation.nodes(num_dimensions, [list(b) for b in sub], n_nodes)
+            pieces.append({"piece_index": multi, "sub_domain": sub, "nodes_per_dim": info["nodes_per_dim"],
+                           "full_grid": info["full_grid"], "shape": info["shape"]})
+        return {"pieces": pieces, "num_pieces": int(np.prod(shape)), "piece_shape": shape}
+
+    @classmethod
+    def from_values(cls, piece_values, num_dimensions: int, domain, n_nodes, knots,
+                    max_derivative_order: int = 2) -> "ChebyshevSpline":
+        """Spline from precomputed value tensors, one per piece in C order over the
+        per-dimension intervals, all of shape ``tuple(n_nodes)`` (reference spline.py:1218-1358).
+        The result has ``function=None`` and is fully built."""
+        if _is_nested(n_nodes):
+            raise NotImplementedError("ChebyshevSpline.from_values() accepts only flat n_nodes "
+                                      "(one int per dim, shared across pieces).")
+        cls._validated_intervals(num_dimensions, domain, knots)
         obj = cls(None, num_dimensions, [list(b) for b in domain], n_nodes=list(n_nodes),
                   knots=[list(k) for k in knots], max_derivative_order=max_derivative_order)
         if len(piece_values) != len(obj._pieces):
@@ -397,8 +425,18 @@ class ChebyshevSpline(DerivativeIdMixin):
     def is_construction_finished(self) -> bool:
         return self._built
 
-    def get_constructor_type(self) -> str:
-        return type(self).__name__
+    def get_used_ns(self) -> list:
+        return [list(v) if isinstance(v, list) else v for v in self.n_nodes]
+
+    def get_error_threshold(self):
+        return self.error_threshold
+
+    def get_num_evaluation_points(self) -> int:
+        return int(sum(int(np.prod(p.n_nodes)) for p in self._pieces))
+
+    def get_evaluation_points(self) -> np.ndarray:
+        """The pieces' grids, piece after piece (reference spline.py:974-987)."""
+        return np.concatenate([p.get_evaluation_points() for p in self._pieces], axis=0)
 
     def get_special_points(self):
         return [list(k) for k in self.knots]

@@ -31,6 +31,7 @@ import numpy as np
 from numpy.polynomial.chebyshev import chebpts1
 
 from . import _lib
+from ._ergonomics import ErgonomicsMixin
 from ._version import __version__
 
 __all__ = ["ChebyshevTT"]
@@ -337,7 +338,7 @@ class _DeviceTT:
             pass
 
 
-class ChebyshevTT:
+class ChebyshevTT(ErgonomicsMixin):
     """Chebyshev interpolation in tensor-train format (signature: reference :1088-1100)."""
 
     def __init__(self, function: Callable, num_dimensions: int,
@@ -646,6 +647,36 @@ class ChebyshevTT:
 
     def is_construction_finished(self) -> bool:
         return self._built
+
+    def get_used_ns(self) -> List[int]:
+        return list(self.n_nodes)
+
+    def get_num_evaluation_points(self) -> int:
+        """Size of the full tensor grid (what a dense build would evaluate)."""
+        return int(np.prod(self.n_nodes))
+
+    def get_evaluation_points(self) -> np.ndarray:
+        """Full Cartesian grid of the storage-frame nodes, rows in C order over the storage
+        dimensions, columns in the user's frame (reference :2775-2800)."""
+        per_dim = [np.sort(0.5 * (a + b) + 0.5 * (b - a) * chebpts1(n))
+                   for (a, b), n in zip(self.domain, self.n_nodes)]
+        grids = np.meshgrid(*per_dim, indexing="ij")
+        cols = [grids[self._dim_order.index(u)] for u in range(self.num_dimensions)]
+        return np.stack([g.ravel() for g in cols], axis=-1).astype(np.float64)
+
+    @staticmethod
+    def nodes(num_dimensions: int, domain, n_nodes) -> dict:
+        """Per-dimension type-I nodes a ``from_values`` tensor must be sampled at (reference :3122-3156)."""
+        from . import Domain, Ns
+        from .barycentric import chebyshev_nodes
+        if isinstance(domain, Domain):
+            domain = list(domain.bounds)
+        if isinstance(n_nodes, Ns):
+            n_nodes = list(n_nodes.counts)
+        if len(domain) != num_dimensions or len(n_nodes) != num_dimensions:
+            raise ValueError(f"domain and n_nodes must have length {num_dimensions}")
+        return {"nodes_per_dim": [chebyshev_nodes(domain[k][0], domain[k][1], n_nodes[k])
+                                  for k in range(num_dimensions)]}
 
     def error_estimate(self) -> float:
         """Sum over dimensions of the largest last Chebyshev coefficient (reference :2469-2504)."""

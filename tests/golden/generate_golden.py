@@ -348,6 +348,7 @@ def main():
         g10[f"{tag}_pivot_value"] = np.array(sl.pivot_value)
         g10[f"{tag}_out"] = np.array([[sl.eval(list(p), s_) for p in pts_] for s_ in case["specs"]])
         g10[f"{tag}_evals"] = np.array(sl.total_build_evals)
+        g10[f"{tag}_err"] = np.array(sl.error_estimate())
     save("g10_sliders", **g10)
 
     # ---------------------------------------------------------------- g11 (slice, row f3)

@@ -297,3 +297,50 @@ def test_sub_interval_quadrature_weights_match_reference():
         w = sub_interval_weights(n, float(tl), float(th))
         assert np.max(np.abs(w - g[f"w{n}"])) < 5e-16 * max(1.0, n / 8), n
     assert np.max(np.abs(sub_interval_weights(9, -1.0, 1.0) - fejer1_weights(9))) < 1e-15
+
+
+# ------------------------------------------------------------------ accessor surface (no device needed)
+def test_accessor_surface_of_all_four_classes():
+    from pychebyshev_amd import ChebyshevSlider, ChebyshevSpline
+    T = np.arange(12.0).reshape(3, 4)
+    a = ChebyshevApproximation.from_values(T, 2, [[0, 1], [2, 4]], [3, 4])
+    tt = ChebyshevTT.from_coeff_cores([np.ones((1, 3, 2)), np.ones((2, 4, 1))], [[0, 1], [2, 4]], dim_order=[1, 0])
+    sp = ChebyshevSpline.from_values([T, T + 1], 2, [[0, 1], [2, 4]], [3, 4], [[0.5], []])
+    for ob in (a, tt, sp):
+        assert ob.get_constructor_type() == type(ob).__name__
+        assert ob.get_descriptor() == "" and ob.get_max_derivative_order() == 2
+        ob.set_descriptor("desk-7")
+        assert ob.get_descriptor() == "desk-7"
+        with pytest.raises(TypeError):
+            ob.set_descriptor(7)
+        assert type(ob).is_dimensionality_allowed(3) and not type(ob).is_dimensionality_allowed(0)
+        assert not type(ob).is_dimensionality_allowed(2.0)
+        twin = ob.clone()
+        assert twin is not ob and twin.get_descriptor() == "desk-7" and twin.function is None
+        twin.set_descriptor("other")
+        assert ob.get_descriptor() == "desk-7"
+    assert a.get_num_evaluation_points() == 12 and a.get_error_threshold() is None and a.get_used_ns() == [3, 4]
+    assert a.clone().tensor_values is not a.tensor_values and np.array_equal(a.clone().tensor_values, T)
+    grid = a.get_evaluation_points()
+    assert grid.shape == (12, 2) and np.array_equal(grid[:4, 0], np.full(4, a.nodes[0][0]))
+    assert tt.get_num_evaluation_points() == 12 and tt.get_used_ns() == [3, 4]
+    g = tt.get_evaluation_points()           # storage dims (n = 3, 4) listed in the USER frame: dim_order [1, 0]
+    assert g.shape == (12, 2) and len(np.unique(g[:, 1])) == 3 and len(np.unique(g[:, 0])) == 4
+    nd = ChebyshevTT.nodes(2, Domain([(0, 1), (2, 4)]), Ns([3, 4]))["nodes_per_dim"]
+    assert np.array_equal(nd[0], chebyshev_nodes(0, 1, 3)) and np.array_equal(nd[1], chebyshev_nodes(2, 4, 4))
+    with pytest.raises(ValueError):
+        ChebyshevTT.nodes(3, [[0, 1]], [3])
+    assert sp.get_num_evaluation_points() == 24 and sp.get_evaluation_points().shape == (24, 2)
+    assert sp.get_used_ns() == [3, 4] and sp.get_error_threshold() is None
+    info = ChebyshevSpline.nodes(2, [[0, 1], [2, 4]], [3, 4], [[0.5], []])
+    assert info["num_pieces"] == 2 and info["piece_shape"] == (2, 1)
+    assert info["pieces"][1]["sub_domain"] == [(0.5, 1), (2, 4)] and info["pieces"][1]["full_grid"].shape == (12, 2)
+    assert np.array_equal(info["pieces"][0]["nodes_per_dim"][0], sp._pieces[0].nodes[0])
+    with pytest.raises(ValueError, match="sorted"):
+        ChebyshevSpline.nodes(1, [[0, 1]], [3], [[0.6, 0.5]])
+    sl = ChebyshevSlider(F.sin_sum_3d, 3, [[-1, 1]] * 3, [4, 3, 5], partition=[[0, 2], [1]], pivot_point=[0.1, 0.2, 0.3])
+    sl.build(verbose=False)
+    assert sl.get_num_evaluation_points() == sl.total_build_evals == 4 * 5 + 3
+    pts = sl.get_evaluation_points()
+    assert pts.shape == (23, 3) and np.all(pts[:20, 1] == 0.2) and np.all(pts[20:, 0] == 0.1) and np.all(pts[20:, 2] == 0.3)
+    assert sl.clone().pivot_point == [0.1, 0.2, 0.3] and sl.clone().function is None

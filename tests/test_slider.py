@@ -61,3 +61,5 @@ def test_slider_eval_matches_reference(tag):
             assert abs(sl.eval(list(pts[i]), s) - ref[i]) <= 1e-12 * scale
     assert np.array_equal(sl.eval_multi(list(pts[5]), case["specs"]), [sl.eval(list(pts[5]), s) for s in case["specs"]])
     assert np.array_equal(sl.eval_batch(pts, case["specs"][0]), batch[:, 0])
+    # sum of the slides' last-coefficient estimates (device contractions per slide)
+    assert abs(sl.error_estimate() - float(g[f"{tag}_err"])) <= 256 * np.finfo(float).eps * fscale
