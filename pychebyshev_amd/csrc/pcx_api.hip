@@ -1412,12 +1412,20 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
         if ((rc = rows.alloc((size_t)m * sizeof(int)))) return rc;
         hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((long)m * m + 255) / 256)), dim3(256), 0, 0, U.as<double>(), m);
         const int mp = (m + 1) & ~1;
+        // squared norm of the largest row bounds sigma_max^2 from below (and sigma_max^2 <= m times it)
+        hipLaunchKernelGGL(k_row_sqnorms, dim3(m), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, N, nrm.as<double>());
+        hnorm.resize(m);
+        HIP_TRY(hipMemcpy(hnorm.data(), nrm.p, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+        double fro2 = 0.0;
+        for (int i = 0; i < m; ++i) fro2 += hnorm[i];
+        const double eps64 = 8.0 * 2.220446049250313e-16;   // rows below 8 eps ||C||_F: noise
+        const double floor2 = eps64 * eps64 * fro2;
         if (m > 1) {
             for (int sweep = 0; sweep < 60; ++sweep) {
                 HIP_TRY(hipMemsetAsync(drot.p, 0, sizeof(int), 0));
                 for (int step = 0; step < mp - 1; ++step)
                     hipLaunchKernelGGL(k_rowjacobi_step, dim3(mp / 2), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, m, N,
-                                       U.as<double>(), step, drot.as<int>());
+                                       U.as<double>(), step, drot.as<int>(), floor2);
                 HIP_TRY(hipGetLastError());
                 int rotated = 0;
                 HIP_TRY(hipMemcpy(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost));

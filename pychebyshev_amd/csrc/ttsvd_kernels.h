@@ -33,9 +33,12 @@ __device__ __forceinline__ double ttsvd_block_sum(double v, double *red) {
 // rows of B (m x N, row stride ldb).  U (m x m, row-major) accumulates the rotations as
 // column operations, so that U B stays equal to the input.  rotated: number of pairs that
 // were not yet orthogonal to working precision.
+// floor2: rows whose squared norm is below it are rounding noise relative to the largest
+// singular value ((8 eps ||C||_F)^2): they are left alone, otherwise the iteration spends
+// dozens of sweeps orthogonalising noise against noise.
 __global__ void __launch_bounds__(TTSVD_THREADS)
 k_rowjacobi_step(double *__restrict__ B, long ldb, int m, long N, double *__restrict__ U,
-                 int step, int *__restrict__ rotated) {
+                 int step, int *__restrict__ rotated, double floor2) {
     __shared__ double red[4];
     const int mp = (m + 1) & ~1;
     const int i = blockIdx.x;
@@ -55,7 +58,7 @@ k_rowjacobi_step(double *__restrict__ B, long ldb, int m, long N, double *__rest
     aa = ttsvd_block_sum(aa, red);
     bb = ttsvd_block_sum(bb, red);
     ab = ttsvd_block_sum(ab, red);
-    if (!(aa > 0.0) || !(bb > 0.0)) return;
+    if (!(aa > floor2) || !(bb > floor2)) return;
     if (__builtin_fabs(ab) <= 1e-15 * __builtin_sqrt(aa) * __builtin_sqrt(bb)) return;
     const double zeta = (bb - aa) / (2.0 * ab);
     const double t = __builtin_copysign(1.0, zeta) / (__builtin_fabs(zeta) + __builtin_sqrt(1.0 + zeta * zeta));
