@@ -149,7 +149,8 @@ int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double *out);
 int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, double *d_out, void *stream);
 int pcx_tt_stream(pcx_tt *h, void **stream);
 /* Kernel selection: 0 = auto, 1 = direct form (one MFMA GEMM over (node, left rank) per
- * dimension; ranks <= 64), 2 = small-rank "W first" form (ranks <= 12, cores in LDS).   */
+ * dimension; ranks <= 64), 2 = small-rank "W first" form (ranks <= 12, cores in LDS).
+ * Models with a rank above 64 always run on a generic wave-per-point kernel.            */
 int pcx_tt_set_kernel(pcx_tt *h, int variant);
 
 /* ---- TT-Cross build steps (tensor_train.py:123-540) ------------------------- */

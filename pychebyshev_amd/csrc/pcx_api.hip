@@ -1053,6 +1053,9 @@ struct pcx_tt {
     long w_resident = 0;  // workgroups of the W-first kernel the device keeps resident (lazy)
     double *d_img = nullptr;
     int variant = 0;      // 0 auto, 1 direct form, 2 W-first form
+    bool generic = false; // ranks > 64: wave-per-point kernel on the plain cores
+    TTGeneric gi;
+    double *d_cores = nullptr;
     std::mutex mu;
     Scratch s_pts, s_out;
     Pinned pin;           // zero-copy staging for small host-pointer batches
@@ -1065,6 +1068,7 @@ extern "C" int pcx_tt_destroy(pcx_tt *h) {
     (void)hipFree(h->d_frag);
     (void)hipFree(h->d_last);
     (void)hipFree(h->d_img);
+    (void)hipFree(h->d_cores);
     h->s_pts.release(); h->s_out.release();
     h->pin.release();
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -1103,7 +1107,29 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
         core_total += (long)ranks[k] * n_nodes[k] * ranks[k + 1];
         h->rmax = std::max(h->rmax, std::max(ranks[k], ranks[k + 1]));
     }
-    if (h->rmax > 64) { delete h; return fail(PCX_ERR_UNSUPPORTED, "TT rank %d > 64 not covered by the MFMA kernel", h->rmax); }
+    if (h->rmax > 64) {
+        // outside the MFMA tilings: the generic wave-per-point kernel on the plain cores
+        if (h->rmax > 4096) { delete h; return fail(PCX_ERR_UNSUPPORTED, "TT rank %d > 4096", h->rmax); }
+        h->generic = true;
+        h->gi.rmax = h->rmax;
+        h->gi.nmax = 1;
+        for (int k = 0; k < d; ++k) {
+            h->gi.rank[k] = ranks[k];
+            h->gi.coff[k] = coff[k];
+            h->gi.nmax = std::max(h->gi.nmax, (int)n_nodes[k]);
+        }
+        h->gi.rank[d] = ranks[d];
+        hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&h->d_cores, core_total * sizeof(double));
+        if (e == hipSuccess) e = hipMemcpy(h->d_cores, cores_cat, core_total * sizeof(double), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            int c = fail(PCX_ERR_HIP, "TT create (generic): %s", hipGetErrorString(e));
+            pcx_tt_destroy(h);
+            return c;
+        }
+        *out = h;
+        return PCX_OK;
+    }
     h->cls = h->rmax <= 16 ? 0 : (h->rmax <= 32 ? 1 : 2);
     // direct form: dim 0 stores one left chunk; later dims are padded to the kernel's
     // compile-time RC chunks x RT tiles so that its node loop is branch-free
@@ -1224,6 +1250,15 @@ static int tt_launch_wfirst_ks(pcx_tt *h, const double *d_pts, long N, double *d
 
 static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
     if (N == 0) return PCX_OK;
+    if (h->generic) {
+        size_t lds = (size_t)4 * (2 * h->gi.rmax + h->gi.nmax) * sizeof(double);
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)k_tt_eval_generic, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        long blocks = std::min<long>((N + 3) / 4, 256L * 8);
+        hipLaunchKernelGGL(k_tt_eval_generic, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->gi, h->d_cores, d_pts, d_out, N);
+        HIP_TRY(hipGetLastError());
+        return PCX_OK;
+    }
     if (h->variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
     if (h->wR && h->variant != 1) {
         if (h->wR == 4) return tt_launch_wfirst_ks<4, 4>(h, d_pts, N, d_out, st);
@@ -1293,6 +1328,7 @@ extern "C" int pcx_tt_set_kernel(pcx_tt *h, int variant) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
     if (variant < 0 || variant > 2) return fail(PCX_ERR_INVALID, "variant %d outside [0, 2]", variant);
     if (variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
+    if (variant != 0 && h->generic) return fail(PCX_ERR_UNSUPPORTED, "ranks above 64 run on the generic kernel only");
     h->variant = variant;
     return PCX_OK;
 }

@@ -216,6 +216,59 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
     }
 }
 
+// Ranks above 64 (outside the MFMA tilings): one wavefront walks one point at a time through
+// the chain with the cores in their natural (r, n, r') layout -- lanes over the right rank b
+// (coalesced core reads from L2), v and the polynomial values in a per-wave LDS slice.
+// LDS per wave: 2 rmax + nmax doubles.
+struct TTGeneric {
+    int rank[PCX_MAX_DIMS + 1];
+    long coff[PCX_MAX_DIMS];
+    int rmax, nmax;
+};
+
+__global__ void __launch_bounds__(256)
+k_tt_eval_generic(TTDims dims, TTGeneric gi, const double *__restrict__ cores,
+                  const double *__restrict__ pts, double *__restrict__ out, long N) {
+    extern __shared__ double lds_g[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    double *va = lds_g + (size_t)wave * (2 * gi.rmax + gi.nmax);
+    double *vb = va + gi.rmax;
+    double *q = vb + gi.rmax;
+    const int d = dims.d;
+    for (long p = (long)blockIdx.x * 4 + wave; p < N; p += (long)gridDim.x * 4) {
+        if (lane == 0) va[0] = 1.0;
+        for (int k = 0; k < d; ++k) {
+            const int rl = gi.rank[k], rr = gi.rank[k + 1], n = dims.n[k];
+            const double x = pts[p * d + dims.col[k]];
+            const double sc = 2.0 * (x - dims.lo[k]) / (dims.hi[k] - dims.lo[k]) - 1.0;   // tensor_train.py:2254
+            if (lane == 0) {                  // T_0 .. T_{n-1} by the forward recurrence
+                double tp = 1.0, tc = sc;
+                for (int j = 0; j < n; ++j) {
+                    q[j] = tp;
+                    const double tn = __builtin_fma(2.0 * sc, tc, -tp);
+                    tp = tc;
+                    tc = tn;
+                }
+            }
+            // wave-private LDS: operations of one wave execute in order, no barrier needed
+            const double *G = cores + gi.coff[k];
+            for (int b = lane; b < rr; b += 64) {
+                double s = 0.0;
+                for (int a = 0; a < rl; ++a) {
+                    const double *ga = G + ((long)a * n) * rr + b;
+                    double w = 0.0;
+                    for (int j = 0; j < n; ++j) w = __builtin_fma(q[j], ga[(long)j * rr], w);
+                    s = __builtin_fma(va[a], w, s);
+                }
+                vb[b] = s;
+            }
+            double *t = va; va = vb; vb = t;
+        }
+        if (lane == 0) out[p] = va[0];
+    }
+}
+
 // _eval_tt (tensor_train.py:223-228) batched over integer grid index tuples: one thread
 // per tuple walks the chain of VALUE cores (cores in their natural (r, n, r') layout).
 __global__ void k_tt_grid_eval(int d, const int *__restrict__ n, const int *__restrict__ ranks,

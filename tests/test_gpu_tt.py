@@ -142,11 +142,23 @@ def test_rank_classes_against_oracle(oracle_mod, ranks, n):
     assert_parity(tt.eval_batch(pts), oracle_mod.tt_eval_batch(cores, dom, pts), 1e-12, str(ranks))
 
 
-def test_unsupported_rank_and_edge_batches():
+def test_ranks_above_64_run_on_the_generic_kernel(oracle_mod):
     rng = np.random.default_rng(0)
-    big = ChebyshevTT.from_coeff_cores([rng.standard_normal((1, 3, 65)), rng.standard_normal((65, 3, 1))], [[0, 1]] * 2)
-    with pytest.raises(NotImplementedError):
-        big.eval_batch(np.zeros((2, 2)))
+    for ranks, n in (([1, 65, 1], [3, 3]), ([1, 70, 100, 33, 1], [5, 11, 4, 7]), ([1, 130, 1], [9, 2])):
+        d = len(n)
+        cores = [rng.standard_normal((ranks[k], n[k], ranks[k + 1])) / np.sqrt(ranks[k] * n[k]) for k in range(d)]
+        dom = [[-1.0, 2.0]] * d
+        order = list(range(d))[::-1]
+        tt = ChebyshevTT.from_coeff_cores(cores, dom, dim_order=order)
+        pts = rng.uniform(-1, 2, (777, d))
+        ref = oracle_mod.tt_eval_batch(cores, dom, pts, dim_order=order)
+        assert_parity(tt.eval_batch(pts), ref, 1e-12, f"generic TT kernel ranks {ranks}")
+        assert abs(tt.eval(list(pts[5])) - ref[5]) <= 1e-12 * np.max(np.abs(ref))
+        t = tt._dev()
+        assert t.lib.pcx_tt_set_kernel(t.handle, 1) != 0      # no MFMA form for these ranks
+
+
+def test_edge_batches():
     g = golden("g4_tt_bs5d")
     tt = ChebyshevTT.from_coeff_cores(_cores(g, "r8_", 5), F.BS5_DOMAIN)
     assert tt.eval_batch(np.zeros((0, 5))).shape == (0,)
