@@ -36,6 +36,8 @@ def gather_results(local: "np.ndarray", n_rows: int, group=None, dst: int = 0):
     per = -(-n_rows // world)
     is_np = isinstance(local, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local
+    if dist.get_backend(group) == "nccl" and t.device.type == "cpu":
+        t = t.cuda()                        # RCCL moves device memory: stage the host block on this rank's GPU
     buf = torch.zeros(per, dtype=t.dtype, device=t.device)   # equal-size blocks for gather
     buf[: t.numel()] = t
     if dist.get_backend(group) == "nccl":
@@ -49,7 +51,7 @@ def gather_results(local: "np.ndarray", n_rows: int, group=None, dst: int = 0):
     if rank != dst:
         return None
     full = out[:n_rows]
-    return full.numpy() if is_np else full
+    return full.cpu().numpy() if is_np else full
 
 
 def eval_sharded(evaluate: Callable[["np.ndarray"], "np.ndarray"], points: "np.ndarray", group=None,

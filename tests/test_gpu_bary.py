@@ -544,3 +544,24 @@ def test_fuzz_random_tensor_shapes_against_oracle(oracle_mod):
         got = c.vectorized_eval_batch(pts, spec)
         scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(T))))
         assert np.max(np.abs(got - ref)) <= 1e-11 * scale, (case, shape, spec, npts)
+
+
+# ------------------------------------------------------------------ sharded evaluation over RCCL (one rank here)
+def test_eval_sharded_over_nccl_with_one_rank(bs5d):
+    """The multi-GPU entry point on its real backend (nccl = RCCL), rehearsed with the single
+    rank a one-GPU box allows; world size 2 is covered on CPU with gloo (test_distributed_cpu.py)."""
+    import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    from pychebyshev_amd.distributed import eval_sharded
+    c, g = bs5d
+    pts = g["points"][:1000]
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        got = eval_sharded(lambda p: c.vectorized_eval_batch(p, [0] * 5), pts)
+    finally:
+        dist.destroy_process_group()
+    assert np.array_equal(got, c.vectorized_eval_batch(pts, [0] * 5))
