@@ -203,29 +203,86 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     const int t_begin = ch0 * PCX_CHUNK_TILES;
     const int t_end = (ch1 * PCX_CHUNK_TILES < plan.MT) ? ch1 * PCX_CHUNK_TILES : plan.MT;
     const bool split = gridDim.y > 1;
+    // Long narrow plans (the 11^5 headline: 31 k-steps) run a hand-pipelined tile loop: fragment
+    // loads stay DEPTH k-steps ahead ACROSS tile boundaries (the first DEPTH fragments of tile t+1
+    // are fetched during the tail of tile t), the row codes of tile t+1 are fetched at the top of
+    // tile t (loads return in order: waiting for codes issued behind a tile's own fragment loads
+    // drained them all, once per tile), and the head-weight look-ups of row j are issued at k-step
+    // 2j and multiplied two k-steps later.  Fences keep hipcc from sinking the loads back to
+    // their uses.  Same arithmetic in the same order as the plain loop below: identical results.
+    constexpr bool PIPELINED = (KS >= 12) && !WIDE;
+    constexpr int DEPTH = 4;
+    unsigned cn[4] = {0u, 0u, 0u, 0u};
+    double head[DEPTH];
+#pragma unroll
+    for (int i = 0; i < DEPTH; ++i) head[i] = 0.0;
+    if (PIPELINED && t_begin < t_end) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cn[j] = rowcode[16 * t_begin + g + 4 * j];
+#pragma unroll
+        for (int i = 0; i < DEPTH; ++i) head[i] = tf[((size_t)t_begin * KS + i) * 64];
+    }
     for (int t = t_begin; t < t_end; ++t) {
         double w[NT][4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned code = rowcode[16 * t + g + 4 * j];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) w[nt][j] = code_weight(code, bw + 16 * nt + c, PW);
-            if (WIDE) {
-                unsigned hi = rowcode_hi[16 * t + g + 4 * j];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w[nt][j] *= code_weight(hi, bw + 16 * nt + c, PW);
-            }
-        }
         pcx_d4 acc[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[nt] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
         const gptr_t tt = tf + (size_t)t * KS * 64;
+        if constexpr (PIPELINED) {
+            const int t_next = (t + 1 < t_end) ? t + 1 : t;
+            const gptr_t tn = tf + (size_t)t_next * KS * 64;
+            double ring[DEPTH];
+            unsigned cc[4];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            double a = tt[s * 64];
+            for (int i = 0; i < DEPTH; ++i) ring[i] = head[i];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt][s], acc[nt], 0, 0, 0);
+            for (int j = 0; j < 4; ++j) { cc[j] = cn[j]; cn[j] = rowcode[16 * t_next + g + 4 * j]; }
+            double wr[4][NT][4];          // raw table entries of row j, looked up at k-step 2j
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const double a = ring[s % DEPTH];
+                if (s + DEPTH < KS) ring[s % DEPTH] = tt[(s + DEPTH) * 64];
+                else head[s + DEPTH - KS] = tn[(s + DEPTH - KS) * 64];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (s == 2 * j) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f)
+                                wr[j][nt][f] = bw[(size_t)((cc[j] >> (8 * f)) & 255u) * PW + 16 * nt + c];
+                    }
+                    if (s == 2 * j + 2) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            w[nt][j] = (wr[j][nt][0] * wr[j][nt][1]) * (wr[j][nt][2] * wr[j][nt][3]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt][s], acc[nt], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned code = rowcode[16 * t + g + 4 * j];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) w[nt][j] = code_weight(code, bw + 16 * nt + c, PW);
+                if (WIDE) {
+                    unsigned hi = rowcode_hi[16 * t + g + 4 * j];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) w[nt][j] *= code_weight(hi, bw + 16 * nt + c, PW);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                double a = tt[s * 64];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt][s], acc[nt], 0, 0, 0);
+            }
         }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)

@@ -547,21 +547,38 @@ def test_fuzz_random_tensor_shapes_against_oracle(oracle_mod):
 
 
 # ------------------------------------------------------------------ sharded evaluation over RCCL (one rank here)
-def test_eval_sharded_over_nccl_with_one_rank(bs5d):
+_NCCL_WORKER = r"""
+import os, sys
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+import numpy as np
+import torch
+import torch.distributed as dist
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests", "golden"))
+import functions as F
+from pychebyshev_amd import ChebyshevApproximation
+from pychebyshev_amd.distributed import eval_sharded
+g = np.load(os.path.join(sys.argv[1], "tests", "golden", "g2_bs5d.npz"))
+c = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES)
+pts = g["points"][:1000]
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+                        device_id=torch.device("cuda", 0))
+try:
+    got = eval_sharded(lambda p: c.vectorized_eval_batch(p, [0] * 5), pts)
+finally:
+    dist.destroy_process_group()
+assert np.array_equal(got, c.vectorized_eval_batch(pts, [0] * 5))
+print("SHARDED-OK")
+"""
+
+
+def test_eval_sharded_over_nccl_with_one_rank():
     """The multi-GPU entry point on its real backend (nccl = RCCL), rehearsed with the single
-    rank a one-GPU box allows; world size 2 is covered on CPU with gloo (test_distributed_cpu.py)."""
-    import os
-    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    import torch
-    import torch.distributed as dist
-    from pychebyshev_amd.distributed import eval_sharded
-    c, g = bs5d
-    pts = g["points"][:1000]
-    torch.cuda.set_device(0)
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
-                            device_id=torch.device("cuda", 0))
-    try:
-        got = eval_sharded(lambda p: c.vectorized_eval_batch(p, [0] * 5), pts)
-    finally:
-        dist.destroy_process_group()
-    assert np.array_equal(got, c.vectorized_eval_batch(pts, [0] * 5))
+    rank a one-GPU box allows; world size 2 is covered on CPU with gloo (test_distributed_cpu.py).
+    Runs in a process of its own, as a rank does (torch brings its own HIP runtime)."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    res = subprocess.run([sys.executable, "-c", _NCCL_WORKER, ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                         text=True, timeout=600)
+    assert res.returncode == 0 and "SHARDED-OK" in res.stdout, res.stderr[-2000:]
