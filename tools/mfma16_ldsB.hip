@@ -50,12 +50,91 @@ __global__ void __launch_bounds__(256, MINW) k(const double *frag, double *out, 
     typedef const double __attribute__((address_space(1))) *gptr_t;
     const gptr_t tf = (gptr_t)frag + lane;
     double total[NT] = {};
+    if (EPI == 8) {
+        // hand-pipelined: fragment loads run DEPTH k-steps ahead ACROSS tile boundaries (the first DEPTH
+        // fragments of tile t+1 are fetched during the tail of tile t), row codes one tile ahead, the
+        // weight look-ups of a tile are issued at its start and multiplied a few k-steps later; fences
+        // keep hipcc from sinking the loads back to their uses
+        constexpr int DEPTH = 6;
+        for (int rep = 0; rep < reps; ++rep) {
+            unsigned cn[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) cn[j] = codes[g + 4 * j];
+            double head[DEPTH];
+#pragma unroll
+            for (int i = 0; i < DEPTH; ++i) head[i] = tf[i * 64];
+            d4 pacc[NT];
+            double pw[NT][4];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                pacc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[nt][j] = 0.0;
+            }
+            for (int t = 0; t < MT; ++t) {
+                const gptr_t tt = tf + (size_t)t * KS * 64;
+                const gptr_t tn = tf + (size_t)((t + 1 < MT) ? t + 1 : t) * KS * 64;
+                double ring[DEPTH];
+#pragma unroll
+                for (int i = 0; i < DEPTH; ++i) ring[i] = head[i];
+                unsigned cc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cc[j] = cn[j];
+                double wr[4][NT][4];          // raw table entries of the tile's weights, row j looked up at k-step 2j
+#pragma unroll
+                for (int j = 0; j < 4; ++j) cn[j] = codes[16 * ((t + 1 < MT) ? t + 1 : t) + g + 4 * j];
+                double w[NT][4];
+                d4 acc[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double a = ring[s % DEPTH];
+                    if (s + DEPTH < KS) ring[s % DEPTH] = tt[(s + DEPTH) * 64];
+                    else head[s + DEPTH - KS] = tn[(s + DEPTH - KS) * 64];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (s == 2 * j) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                                for (int f = 0; f < 4; ++f) wr[j][nt][f] = hw[((cc[j] >> (8 * f)) & 255u) * PW + 16 * nt + c];
+                        }
+                        if (s == 2 * j + 2) {
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) w[nt][j] = (wr[j][nt][0] * wr[j][nt][1]) * (wr[j][nt][2] * wr[j][nt][3]);
+                        }
+                    }
+                    if (s == 10) {      // fold the previous tile while this one multiplies
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) total[nt] = __builtin_fma(pacc[nt][j], pw[nt][j], total[nt]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt < NR ? nt : 0][NR > 0 ? s : 0], acc[nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    pacc[nt] = acc[nt];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pw[nt][j] = w[nt][j];
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) total[nt] = __builtin_fma(pacc[nt][j], pw[nt][j], total[nt]);
+        }
+    } else
     if (EPI == 7) {
         // hand-pipelined: fragment loads run DEPTH k-steps ahead ACROSS tile boundaries (the first DEPTH
         // fragments of tile t+1 are fetched during the tail of tile t), row codes one tile ahead, the
         // weight look-ups of a tile are issued at its start and multiplied a few k-steps later; fences
         // keep hipcc from sinking the loads back to their uses
-        constexpr int DEPTH = 8;
+        constexpr int DEPTH = 6;
         for (int rep = 0; rep < reps; ++rep) {
             unsigned cn[4];
 #pragma unroll
@@ -273,6 +352,6 @@ int main() {
     for (int i = 0; i < MT * 16; ++i) hc[i] = (unsigned)(i % 11) | ((11 + (i / 11) % 11) << 8) | ((22 + (i / 121) % 11) << 16) | (33u << 24);
     hipMalloc(&codes, sizeof(hc)); hipMemcpy(codes, hc, sizeof(hc), hipMemcpyHostToDevice);
     run<0, 2, 2>(frag); run<0, 2, 2, 1>(frag, codes); run<0, 2, 2, 2>(frag, codes);
-    run<0, 2, 2, 3>(frag, codes); run<0, 2, 2, 5>(frag, codes); run<0, 2, 2, 7>(frag, codes);
+    run<0, 2, 2, 3>(frag, codes); run<0, 2, 2, 7>(frag, codes); run<0, 2, 2, 8>(frag, codes);
     return 0;
 }
