@@ -41,3 +41,21 @@ for n in (1, 10, 100, 1000, 10_000, 100_000, 1_000_000):
         tt.eval_batch(p)
     dt2 = (time.perf_counter() - t0) / reps
     print(f"host-pointer batch N={n:8d}: barycentric {dt * 1e3:9.4f} ms ({n / dt:10.3e} pts/s)   TT {dt2 * 1e3:9.4f} ms ({n / dt2:10.3e} pts/s)")
+
+# build times next to the reference's published ones (docs/benchmarks.md there: TT-Cross max_rank=15 0.35 s,
+# barycentric 161,051-callback build 0.35 s)
+for mr in (8, 15):
+    b = ChebyshevTT(F.bs_5d, 5, F.BS5_DOMAIN, F.BS5_NODES, max_rank=mr)
+    t0 = time.perf_counter(); b.build(verbose=False, seed=42); dt = time.perf_counter() - t0
+    print(f"TT-Cross build max_rank={mr:2d} seed 42: {dt:.3f} s, ranks {b.tt_ranks}, {b.total_build_evals} unique evaluations")
+# the reference's accuracy check (compare_tensor_train.py:230-247 there): 50 points, generator seed 42, one
+# uniform column per dimension, only prices above $0.50 count
+p50 = F.bs5_query_points(50, seed=42)
+exact = np.array([F.bs_5d(list(p)) for p in p50])
+keep = np.abs(exact) >= 0.50
+err = np.abs(b.eval_batch(p50)[keep] - exact[keep]) / np.abs(exact[keep]) * 100
+print(f"TT (max_rank 15) price error over {keep.sum()} of 50 seed-42 points (price > $0.50): mean {err.mean():.3f} %, "
+      f"max {err.max():.3f} %  (reference publishes 0.002 % / 0.014 %)")
+c2 = ChebyshevApproximation(F.bs_5d, 5, F.BS5_DOMAIN, F.BS5_NODES)
+t0 = time.perf_counter(); c2.build(verbose=False); dt = time.perf_counter() - t0
+print(f"barycentric build, 161,051 Python callbacks: {dt:.3f} s")
