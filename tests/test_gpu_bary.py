@@ -561,7 +561,7 @@ g = np.load(os.path.join(sys.argv[1], "tests", "golden", "g2_bs5d.npz"))
 c = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES)
 pts = g["points"][:1000]
 torch.cuda.set_device(0)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29541", rank=0, world_size=1,
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1,
                         device_id=torch.device("cuda", 0))
 try:
     got = eval_sharded(lambda p: c.vectorized_eval_batch(p, [0] * 5), pts)
@@ -576,9 +576,13 @@ def test_eval_sharded_over_nccl_with_one_rank():
     """The multi-GPU entry point on its real backend (nccl = RCCL), rehearsed with the single
     rank a one-GPU box allows; world size 2 is covered on CPU with gloo (test_distributed_cpu.py).
     Runs in a process of its own, as a rank does (torch brings its own HIP runtime)."""
+    import socket
     import subprocess
     import sys
     from conftest import ROOT
-    res = subprocess.run([sys.executable, "-c", _NCCL_WORKER, ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+    with socket.socket() as sock:                 # a free rendezvous port
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    res = subprocess.run([sys.executable, "-c", _NCCL_WORKER, ROOT, port], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                          text=True, timeout=600)
     assert res.returncode == 0 and "SHARDED-OK" in res.stdout, res.stderr[-2000:]
