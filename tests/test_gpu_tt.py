@@ -256,8 +256,12 @@ def test_tt_cross_build_bs5d_matches_reference(mr, sweeps, capsys):
     exact = np.array([F.bs_5d(list(p)) for p in pts])
     assert np.max(np.abs(tt.eval_batch(pts) - exact) / exact) < 1e-2
     fd = np.array([tt.eval_multi(list(s), g["fd_specs"].tolist()[:4]) for s in g["scenarios"]])
-    assert np.allclose(fd[:, 0], g[f"r{mr}_fd"][:, 0], rtol=0, atol=1e-5)
-    assert np.allclose(fd[:, 1], g[f"r{mr}_fd"][:, 1], rtol=0, atol=1e-3)
+    # value / delta / gamma by central differences on OUR build vs the reference's on ITS build: the two
+    # builds agree to ~1e-9 (different SVD and maxvol arithmetic), amplified by 1/h and 1/h^2 (h = 4e-3)
+    ref_fd = g[f"r{mr}_fd"]
+    assert np.max(np.abs(fd[:, 0] - ref_fd[:, 0])) <= 1e-7
+    assert np.max(np.abs(fd[:, 1] - ref_fd[:, 1])) <= 1e-6
+    assert np.max(np.abs(fd[:, 2] - ref_fd[:, 2])) <= 1e-4
 
 
 def test_tt_cross_build_small_cases_match_reference():
