@@ -1045,7 +1045,8 @@ struct pcx_tt {
     int rmax = 1;
     int cls = 0;  // 0: RC<=4,RT=1,NT=4   1: RC<=8,RT=2,NT=2   2: RC<=16,RT=4,NT=1
     double *d_frag = nullptr;
-    double *d_last = nullptr;   // plain last core [a][j] (right rank 1) for the VALU tail
+    double *d_last = nullptr;   // last core [a][j] (right rank 1), zero-padded to 4 RC rows, for the VALU tail
+    long last_lds_doubles = 0;  // its size when it is small enough to be copied to LDS, else 0
     int rl_last = 1;
     // small-rank "W first" form (ranks <= 12, packed cores resident in LDS)
     int wR = 0;           // 0 = not available, else padded rank 4 / 8 / 12
@@ -1159,8 +1160,17 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
     CREATE_TRY(hipMalloc((void **)&d_cores, core_total * sizeof(double)));
     CREATE_TRY(hipMemcpy(d_cores, cores_cat, core_total * sizeof(double), hipMemcpyHostToDevice));
     h->rl_last = ranks[d - 1];
-    CREATE_TRY(hipMalloc((void **)&h->d_last, (size_t)ranks[d - 1] * n_nodes[d - 1] * sizeof(double)));
-    CREATE_TRY(hipMemcpy(h->d_last, cores_cat + coff[d - 1], (size_t)ranks[d - 1] * n_nodes[d - 1] * sizeof(double), hipMemcpyHostToDevice));
+    {
+        // the last core as an [a][j] table zero-padded to the direct kernel's 4 RC rows
+        const int RCk = h->cls == 0 ? (h->rmax + 3) / 4 : (h->cls == 1 ? 8 : 16);
+        const size_t rows = (size_t)4 * RCk, nl = (size_t)n_nodes[d - 1];
+        std::vector<double> padded(rows * nl, 0.0);
+        for (size_t a = 0; a < (size_t)ranks[d - 1]; ++a)
+            for (size_t j = 0; j < nl; ++j) padded[a * nl + j] = cores_cat[coff[d - 1] + a * nl + j];
+        CREATE_TRY(hipMalloc((void **)&h->d_last, padded.size() * sizeof(double)));
+        CREATE_TRY(hipMemcpy(h->d_last, padded.data(), padded.size() * sizeof(double), hipMemcpyHostToDevice));
+        h->last_lds_doubles = (padded.size() * sizeof(double) <= 16 * 1024) ? (long)padded.size() : 0;
+    }
     for (int k = 0; k < d; ++k) {
         long cnt = (long)n_nodes[k] * h->rk.rc[k] * h->rk.rt[k] * 64;
         hipLaunchKernelGGL(k_tt_pack_core, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream,
@@ -1269,8 +1279,9 @@ static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipS
         long per_wg = 4L * 16 * nt;
         long blocks = (N + per_wg - 1) / per_wg;
         if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
-        size_t lds = (size_t)4 * 16 * nt * h->dims.d * sizeof(double);   // the workgroup's query rows
-        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->rk, h->d_frag, h->d_last, h->rl_last, d_pts, d_out, N);
+        size_t lds = ((size_t)4 * 16 * nt * h->dims.d + (size_t)h->last_lds_doubles) * sizeof(double);   // query rows + last core
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->rk, h->d_frag, h->d_last,
+                           h->last_lds_doubles ? h->rl_last : 0, d_pts, d_out, N);
         HIP_TRY(hipGetLastError());
         return PCX_OK;
     };

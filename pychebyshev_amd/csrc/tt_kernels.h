@@ -132,6 +132,11 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
         const int cnt = 16 * NT * d;
         for (int i = lane; i < cnt; i += 64) xs[i] = (i < avail) ? pts[first + i] : 0.0;
     }
+    // small last cores (4 RC rows x n, zero padded) are copied behind the query rows
+    double *gl_lds = lds_x + (size_t)4 * (16 * NT) * d;
+    const bool last_in_lds = (rl_last != 0);       // the host passes 0 when the table does not fit
+    if (last_in_lds)
+        for (int i = threadIdx.x; i < 4 * RC * dims.n[d - 1]; i += 256) gl_lds[i] = glast[i];
     __syncthreads();
 
     double v[NT][RC];
@@ -180,35 +185,44 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
             for (int c = 0; c < RC; ++c) v[nt][c] = acc[nt][c >> 2][c & 3];
     }
 
-    // last dimension: y = sum_a v[a] * sum_j T_j(s) G[a][j]; lane group g owns a = 4c + g
+    // last dimension: y = sum_a v[a] * sum_j T_j(s) G[a][j]; lane group g owns a = 4c + g.
+    // `glast` is the last core zero-padded to 4 RC rows ([a][j]): no rank predicate, one table read
+    // per (j, c) shared by the NT column tiles; small tables are read from the LDS copy made above.
     {
         const int k = d - 1;
         const int n = dims.n[k];
         const double lo = dims.lo[k], hi = dims.hi[k];
+        double sc[NT], tp[NT], tc[NT], w[NT][RC];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            double x = xs[(16 * nt + c16) * d + dims.col[k]];
+            sc[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;
+            tp[nt] = 1.0;
+            tc[nt] = sc[nt];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) w[nt][c] = 0.0;
+        }
+        const double *gl = last_in_lds ? (const double *)gl_lds : glast;
+        for (int j = 0; j < n; ++j) {
+            double gv[RC];
+#pragma unroll
+            for (int c = 0; c < RC; ++c) gv[c] = gl[(4 * c + g) * n + j];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const double q = tp[nt];                   // T_j; (tp, tc) = (T_j, T_{j+1})
+#pragma unroll
+                for (int c = 0; c < RC; ++c) w[nt][c] = __builtin_fma(q, gv[c], w[nt][c]);
+                const double tn = __builtin_fma(2.0 * sc[nt], tc[nt], -tp[nt]);
+                tp[nt] = tc[nt];
+                tc[nt] = tn;
+            }
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             long p = base + 16 * nt + c16;
-            double x = xs[(16 * nt + c16) * d + dims.col[k]];
-            double sc = 2.0 * (x - lo) / (hi - lo) - 1.0;
-            double w[RC];
-#pragma unroll
-            for (int c = 0; c < RC; ++c) w[c] = 0.0;
-            double tp = 1.0, tc = sc;
-            for (int j = 0; j < n; ++j) {
-                const double q = tp;                       // T_j; (tp, tc) = (T_j, T_{j+1})
-#pragma unroll
-                for (int c = 0; c < RC; ++c) {
-                    int a = 4 * c + g;
-                    double gv = (a < rl_last) ? glast[a * n + j] : 0.0;
-                    w[c] = __builtin_fma(q, gv, w[c]);
-                }
-                const double tn = __builtin_fma(2.0 * sc, tc, -tp);
-                tp = tc;
-                tc = tn;
-            }
             double y = 0.0;
 #pragma unroll
-            for (int c = 0; c < RC; ++c) y = __builtin_fma(v[nt][c], w[c], y);
+            for (int c = 0; c < RC; ++c) y = __builtin_fma(v[nt][c], w[nt][c], y);
             y += __shfl_xor(y, 16, 64);
             y += __shfl_xor(y, 32, 64);
             if (g == 0 && p < N) out[p] = y;
