@@ -210,15 +210,18 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     // drained them all, once per tile), and the head-weight look-ups of row j are issued at k-step
     // 2j and multiplied two k-steps later.  Fences keep hipcc from sinking the loads back to
     // their uses.  Same arithmetic in the same order as the plain loop below: identical results.
-    constexpr bool PIPELINED = (KS >= 12) && !WIDE;
+    constexpr bool PIPELINED = (KS >= 12);
     constexpr int DEPTH = 6;           // <= 12 <= KS: the ring never wraps a tile (A/B on one box: 4 -0.6 %, 8 -0.3 %)
-    unsigned cn[4] = {0u, 0u, 0u, 0u};
+    unsigned cn[4] = {0u, 0u, 0u, 0u}, cnh[4] = {0u, 0u, 0u, 0u};
     double head[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) head[i] = 0.0;
     if (PIPELINED && t_begin < t_end) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cn[j] = rowcode[16 * t_begin + g + 4 * j];
+        for (int j = 0; j < 4; ++j) {
+            cn[j] = rowcode[16 * t_begin + g + 4 * j];
+            if (WIDE) cnh[j] = rowcode_hi[16 * t_begin + g + 4 * j];
+        }
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) head[i] = tf[((size_t)t_begin * KS + i) * 64];
     }
@@ -232,12 +235,17 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             const int t_next = (t + 1 < t_end) ? t + 1 : t;
             const gptr_t tn = tf + (size_t)t_next * KS * 64;
             double ring[DEPTH];
-            unsigned cc[4];
+            unsigned cc[4], cch[4];
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) ring[i] = head[i];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { cc[j] = cn[j]; cn[j] = rowcode[16 * t_next + g + 4 * j]; }
+            for (int j = 0; j < 4; ++j) {
+                cc[j] = cn[j];
+                cn[j] = rowcode[16 * t_next + g + 4 * j];
+                if (WIDE) { cch[j] = cnh[j]; cnh[j] = rowcode_hi[16 * t_next + g + 4 * j]; }
+            }
             double wr[4][NT][4];          // raw table entries of row j, looked up at k-step 2j
+            double wh[4][NT][4];          // ... and of its second code word (wide plans), at k-step 2j + 1
 #pragma unroll
             for (int s = 0; s < KS; ++s) {
                 const double a = ring[s % DEPTH];
@@ -256,6 +264,18 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
                             w[nt][j] = (wr[j][nt][0] * wr[j][nt][1]) * (wr[j][nt][2] * wr[j][nt][3]);
+                    }
+                    if (WIDE && s == 2 * j + 1) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f)
+                                wh[j][nt][f] = bw[(size_t)((cch[j] >> (8 * f)) & 255u) * PW + 16 * nt + c];
+                    }
+                    if (WIDE && s == 2 * j + 3) {
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt)
+                            w[nt][j] *= (wh[j][nt][0] * wh[j][nt][1]) * (wh[j][nt][2] * wh[j][nt][3]);
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);
