@@ -392,3 +392,23 @@ def test_fuzz_random_tt_models_against_oracle(oracle_mod):
         got = tt.eval_batch(pts)
         scale = max(float(np.max(np.abs(ref))), 1e-300)
         assert np.max(np.abs(got - ref)) <= 2e-12 * scale, (case, d, ranks, n, order, npts)
+
+
+def test_svd_and_cross_builds_agree_and_hit_the_closed_form():
+    """The reference's own acceptance pattern (test_tensor_train.py:39-66, 293-302 there): on the 3-D
+    sin sum the SVD build is accurate to 1e-8, the cross build to 1e-6, and the two agree to 1e-6."""
+    import math
+    svd = ChebyshevTT(F.sin_sum_3d, 3, [[-1, 1]] * 3, [11, 11, 11], max_rank=5)
+    svd.build(verbose=False, method="svd")
+    cross = ChebyshevTT(F.sin_sum_3d, 3, [[-1, 1]] * 3, [11, 11, 11], max_rank=5)
+    cross.build(verbose=False, seed=42)
+    assert svd.tt_ranks == [1, 2, 2, 1] and svd.total_build_evals == 11 ** 3 and svd.method == "svd"
+    pts = np.random.default_rng(8).uniform(-1, 1, (500, 3))
+    exact = np.sin(pts).sum(axis=1)
+    assert np.max(np.abs(svd.eval_batch(pts) - exact)) < 1e-8
+    assert np.max(np.abs(cross.eval_batch(pts) - exact)) < 1e-6
+    assert np.max(np.abs(svd.eval_batch(pts) - cross.eval_batch(pts))) < 1e-6
+    # batch == loop of eval at 1e-12 (test_tensor_train.py:105-121 there)
+    one_by_one = np.array([svd.eval(list(p)) for p in pts[:50]])
+    assert np.max(np.abs(one_by_one - svd.eval_batch(pts[:50]))) <= 1e-12
+    assert abs(svd.eval([0.1, 0.2, 0.3]) - (math.sin(0.1) + math.sin(0.2) + math.sin(0.3))) < 1e-8
