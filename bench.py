@@ -2,146 +2,213 @@
 """bench.py -- headline benchmark: 5-D Black-Scholes barycentric point-evals/sec on MI355X.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W
-  N = 1   : single process, no torch -- the C ABI (libpcx_hip.so) does everything.
-  N > 1   : launched by torch.distributed.run, one rank per GPU; torch is plumbing only
-            (rendezvous, barrier, max-over-ranks, the RCCL gather of the result blocks).
+  No PyTorch anywhere: the C ABI (libpcx_hip.so) does the compute, the RCCL gather
+  (pcx_comm_*) and the copies; ranks meet through pychebyshev_amd.distributed.HostGroup.
+  N = 1   : one process.
+  N > 1   : one process per GPU.  Either the driver starts the ranks
+            (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`, used
+            as a plain process launcher: RANK / LOCAL_RANK / WORLD_SIZE come from the
+            environment), or -- when WORLD_SIZE is unset -- this script starts N child
+            ranks itself BEFORE touching the GPU and forwards rank 0's JSON line.
 
 A "step" is one pass of the hot path over one batch already resident in HBM:
   workload bary5d (default, BASELINE.json configs[1]): 5-D Black-Scholes n=11^5 full
   tensor, 10^6 fp64 query points per GPU (seed 99 + rank, column-wise uniform), value
-  spec.  Other workloads (--workload greeks5d | tt5d | tt10d) are the parity-test
-  configs, runnable for profiling; they are not the headline line.
+  spec.  Other workloads (--workload greeks5d | tt5d | tt10d) are the other BASELINE
+  configs; config 5 per GPU is `--workload tt10d --points 12500000`.
 
-Weak scaling: every rank owns its own 10^6-point batch; value = all points of all ranks
-/ max-over-ranks wall time of the K steps (barrier + device sync on both sides).  With
-N > 1 each step ends with the gather of the N result blocks on rank 0 (the path's only
-collective, inside the timed region).
+Weak scaling: every rank owns its own batch; value = all point-evals of all ranks /
+max-over-ranks wall time of the K steps (host barrier + device sync on both sides).  With
+N > 1 each timed step ends with the RCCL gather of the N result blocks on rank 0's GPU (the
+path's only exchange; it overlaps the next step's kernel).  The same K steps are timed
+again (a) without any gather, (b) with rank 0 downloading the gathered result, and (c) with
+every rank downloading its block straight into one pinned shared-memory host array (no
+collective) -- reported under "gather" beside the headline.
 
 Also on the JSON line:
-  roofline     dominant kernel (k_bary_mfma): algorithmic flop per launch / mean launch
-               duration from HIP events recorded on the launch stream, vs the FP64 MFMA peak.
-  cpu_baseline the CPU oracle (C restatement of the reference, OpenMP over all host
-               cores) timed on a bounded sample of the same workload, rank 0, N = 1 only.
+  roofline     dominant kernel: algorithmic flop per launch / mean launch duration from
+               HIP events on the launch stream, vs the FP64 MFMA peak; `traffic` is the
+               HBM bytes per launch from the committed PMC profile (cached; see
+               traffic_source), not collected in this run.
+  end_to_end   the host-pointer entry point on the same batch (H2D + kernel + D2H).
+  greeks, tt   companions: config 4 (6 derivative specs) and config 3 (TT-Cross build +
+               10^7-point eval_batch), same timing discipline, never mixed into `value`.
+  cpu_baseline the CPU oracle (C restatement of the reference, OpenMP) on all usable
+               host cores, on the per-GPU CPU share (16) and the reference's NumPy shape on
+               one core -- bounded samples of the same workload, rank 0, N = 1 only.
 """
 from __future__ import annotations
 
 import argparse
 import ctypes
 import json
+import math
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
-
-import functions as F  # noqa: E402  (analytic Black-Scholes + the seed-99 point recipe)
-from pychebyshev_amd import ChebyshevApproximation, ChebyshevTT, _lib  # noqa: E402
 
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (= FP64 vector peak), AMD spec;
                                   # v_mfma_f64_16x16x4_f64 at 64 cycles/SIMD x 1024 SIMDs x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
+METRIC = "point-evals/sec, 5D Black-Scholes n=11^5 barycentric + TT, 1/2/4/8 GPU"
+
+# ----------------------------------------------------------------------------------
+# synthetic workload definitions (own code; the reference's benchmark recipe is
+# compare_methods_time_accuracy.py:36-43,64-72,233-254 and tests/conftest.py:86-100 there)
+# ----------------------------------------------------------------------------------
+BS5_DOMAIN = [[80.0, 120.0], [90.0, 110.0], [0.25, 1.0], [0.15, 0.35], [0.01, 0.08]]
+BS5_NODES = [11, 11, 11, 11, 11]
+BS_Q = 0.02
+GREEK_SPECS = [[0, 0, 0, 0, 0],   # price
+               [1, 0, 0, 0, 0],   # delta
+               [2, 0, 0, 0, 0],   # gamma
+               [0, 0, 0, 1, 0],   # vega
+               [0, 0, 1, 0, 0],   # dV/dT
+               [0, 0, 0, 0, 1]]   # rho
+GREEK_NAMES = ["price", "delta", "gamma", "vega", "dV/dT", "rho"]
 
 
-def cpu_threads() -> int:
-    """Threads for the CPU baseline: the box's per-GPU CPU share (16), or fewer."""
-    return max(1, min(os.cpu_count() or 1, int(os.environ.get("PCX_CPU_THREADS", "16"))))
+def bs_5d(x, _=None):
+    """European call V(S, K, T, sigma, r), dividend yield 0.02 (math.erfc closed form)."""
+    S, K, T, sigma, r = x
+    sq = sigma * math.sqrt(T)
+    d1 = (math.log(S / K) + (r - BS_Q + 0.5 * sigma * sigma) * T) / sq
+    ncdf = lambda v: 0.5 * math.erfc(-v / math.sqrt(2.0))
+    return S * math.exp(-BS_Q * T) * ncdf(d1) - K * math.exp(-r * T) * ncdf(d1 - sq)
+
+
+def uniform_points(domain, n, seed):
+    """One rng.uniform(lo, hi, n) per dimension, stacked column-wise (the reference's recipe)."""
+    rng = np.random.default_rng(seed)
+    return np.column_stack([rng.uniform(lo, hi, n) for lo, hi in domain])
+
+
+def usable_cores() -> int:
+    """Host cores this process may use: CPU affinity capped by a cgroup CPU quota."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            quota, period = open(path).read().split()[:2]
+            if quota != "max":
+                n = min(n, max(1, int(int(quota) / int(period))))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
 
 
 # ----------------------------------------------------------------------------------
 # workloads
 # ----------------------------------------------------------------------------------
-def bs5d_tensor() -> np.ndarray:
-    info = ChebyshevApproximation.nodes(5, F.BS5_DOMAIN, F.BS5_NODES)
-    vals = np.array([F.bs_5d(list(p)) for p in info["full_grid"]])
-    return vals.reshape(info["shape"])
-
-
 class Workload:
     name = ""
+    key = ""
     d = 0
     points_per_gpu = 0
-    evals_per_point = 1          # point-evals per query point per step
+    evals_per_point = 1          # point-evals per query point per step (= kernel launches per step)
     flop_per_eval = 0.0          # algorithmic flop per point-eval (SURVEY.md 8d)
     bytes_per_eval = 0.0         # algorithmic HBM bytes per point-eval
     kernel = ""
-
-    def points(self, rank: int) -> np.ndarray:
-        raise NotImplementedError
-
-    def launch(self, d_pts, n, d_out, stream):
-        raise NotImplementedError
+    build_info = None
 
 
 class Bary5D(Workload):
-    name = "5D Black-Scholes n=11^5 full-tensor barycentric, 1M fp64 queries per GPU"
     d = 5
     flop_per_eval = 354310.0     # 177,155 FMA: 161051 + 14641 + 1331 + 121 + 11
     bytes_per_eval = 48.0        # 5 x 8 in + 8 out
     kernel = "k_bary_mfma<31,2,false>"
 
-    def __init__(self, n_points, specs=((0, 0, 0, 0, 0),)):
+    def __init__(self, lib_mod, n_points, specs, key):
+        from pychebyshev_amd import ChebyshevApproximation
+        self._lib = lib_mod
+        self.key = key
         self.points_per_gpu = n_points
         self.specs = [list(s) for s in specs]
         self.evals_per_point = len(self.specs)
-        self.model = ChebyshevApproximation.from_values(bs5d_tensor(), 5, F.BS5_DOMAIN, F.BS5_NODES)
+        self.name = ("5D Black-Scholes n=11^5 full-tensor barycentric, %s fp64 queries per GPU%s"
+                     % (f"{n_points:,}", "" if len(specs) == 1 else f" x {len(specs)} derivative specs (price + 5 Greeks)"))
+        info = ChebyshevApproximation.nodes(5, BS5_DOMAIN, BS5_NODES)
+        tensor = np.array([bs_5d(list(p)) for p in info["full_grid"]]).reshape(info["shape"])
+        self.model = ChebyshevApproximation.from_values(tensor, 5, BS5_DOMAIN, BS5_NODES)
         self.model.to_device()
         self.m = self.model._model()
-        self.spec_arrays = [_lib.i32(s) for s in self.specs]
+        self.spec_arrays = [lib_mod.i32(s) for s in self.specs]
 
     def points(self, rank):
-        return F.bs5_query_points(self.points_per_gpu, seed=99 + rank)
+        return uniform_points(BS5_DOMAIN, self.points_per_gpu, 99 + rank)
 
     def stream(self):
         st = ctypes.c_void_p()
-        _lib.check(self.m.lib.pcx_bary_stream(self.m.handle, ctypes.byref(st)), self.m.lib)
+        self._lib.check(self.m.lib.pcx_bary_stream(self.m.handle, ctypes.byref(st)), self.m.lib)
         return st
 
-    def launch(self, d_pts, n, d_out, stream):
+    def launch(self, d_pts, n, d_out, stream, which=None):
+        """One launch per derivative spec; spec i writes out[i*n : (i+1)*n]."""
         for i, s in enumerate(self.spec_arrays):
+            if which is not None and i != which:
+                continue
             out_i = ctypes.c_void_p(d_out.value + i * n * 8)
-            _lib.check(self.m.lib.pcx_bary_eval_batch_dev(self.m.handle, d_pts, n, _lib.p_i32(s), out_i, stream),
-                       self.m.lib)
+            self._lib.check(self.m.lib.pcx_bary_eval_batch_dev(self.m.handle, d_pts, n, self._lib.p_i32(s),
+                                                               out_i, stream), self.m.lib)
 
-    def oracle_rate(self, seconds=12.0):
+    def host_eval(self, pts):
+        """The host-pointer entry point (what ChebyshevApproximation.vectorized_eval_batch calls)."""
+        return [self.model.vectorized_eval_batch(pts, s) for s in self.specs]
+
+    def cpu_rates(self, seconds):
         import oracle
         om = oracle.BaryModel(self.model.nodes, self.model.weights, self.model.diff_matrices,
                               self.model.tensor_values)
-        pts = F.bs5_query_points(self.points_per_gpu, seed=99)
-        oracle.set_num_threads(cpu_threads())
-        probe = 4000
-        oracle.bary_eval_batch(om, pts[:probe], self.specs[0])          # thread start-up
-        probe = 20000
+        pts = self.points(0)
+        nspec = len(self.specs)
+
+        def c_port(threads, budget):
+            oracle.set_num_threads(threads)
+            oracle.bary_eval_batch(om, pts[:4000], self.specs[0])           # thread start-up
+            probe = 20000
+            t0 = time.perf_counter()
+            oracle.bary_eval_batch(om, pts[:probe], self.specs[0])
+            rate = probe / (time.perf_counter() - t0)
+            sample = int(min(len(pts), max(probe, rate * budget / nspec)))
+            t0 = time.perf_counter()
+            for s in self.specs:
+                oracle.bary_eval_batch(om, pts[:sample], s)
+            dt = time.perf_counter() - t0
+            return {"value": sample * nspec / dt, "unit": "point-evals/s", "cores": oracle.num_threads(),
+                    "kind": "port",
+                    "sample": f"first {sample} of rank 0's seed-99 points x {nspec} spec(s), {dt:.1f} s"}
+
+        npn = 2000
         t0 = time.perf_counter()
-        oracle.bary_eval_batch(om, pts[:probe], self.specs[0])
-        rate = probe / (time.perf_counter() - t0)
-        sample = int(min(len(pts), max(probe, rate * seconds / len(self.specs))))
-        t0 = time.perf_counter()
-        for s in self.specs:
-            oracle.bary_eval_batch(om, pts[:sample], s)
-        dt = time.perf_counter() - t0
-        # the reference's own algorithm shape (Python loop of NumPy matvecs), one core
-        npn = 3000
-        t0 = time.perf_counter()
-        oracle.bary_eval_batch_numpy(om, pts[:npn], self.specs[0])
-        self.numpy_loop = {"value": npn / (time.perf_counter() - t0), "unit": "point-evals/s", "cores": 1,
-                           "sample": f"first {npn} points, per-point NumPy loop as in the reference"}
-        return sample * len(self.specs) / dt, oracle.num_threads(), \
-            f"first {sample} of the 10^6 seed-99 points x {len(self.specs)} spec(s), {dt:.1f} s"
+        for s in self.specs[:1]:
+            oracle.bary_eval_batch_numpy(om, pts[:npn], s)
+        numpy_loop = {"value": npn / (time.perf_counter() - t0), "unit": "point-evals/s", "cores": 1,
+                      "sample": f"first {npn} points, per-point NumPy matvec loop in the reference's shape "
+                                "(barycentric.py:1035-1046), default BLAS threads"}
+        return c_port, numpy_loop
 
 
 class TTWork(Workload):
-    def __init__(self, n_points, kind):
+    def __init__(self, lib_mod, n_points, kind):
+        from pychebyshev_amd import ChebyshevTT
+        self._lib = lib_mod
+        self.key = kind
         self.points_per_gpu = n_points
-        self.build_info = None
         if kind == "tt5d":
             # config 3 = TT-Cross build (max_rank 8, seed 42) + batched queries: the model is built
             # here, through the Python callback and the device-side cross steps, and timed
             g = np.load(os.path.join(ROOT, "tests", "golden", "g4_tt_bs5d.npz"))
-            built = ChebyshevTT(F.bs_5d, 5, F.BS5_DOMAIN, F.BS5_NODES, max_rank=8)
+            built = ChebyshevTT(bs_5d, 5, BS5_DOMAIN, BS5_NODES, max_rank=8)
             t0 = time.perf_counter()
             built.build(verbose=False, seed=42)
             self.build_info = {"method": "cross", "seconds": time.perf_counter() - t0,
@@ -149,16 +216,18 @@ class TTWork(Workload):
                                "reference_ranks": [int(v) for v in g["r8_ranks"]],
                                "reference_unique_evals": int(g["r8_evals"])}
             cores = built._coeff_cores
-            self.domain = F.BS5_DOMAIN
-            self.name = "5D Black-Scholes ChebyshevTT ranks [1,8,8,8,6,1] eval_batch"
-            self.flop_per_eval, self.bytes_per_eval = 4560.0, 48.0
+            self.domain = BS5_DOMAIN
+            self.name = "5D Black-Scholes ChebyshevTT ranks %s eval_batch, %s fp64 queries per GPU" % (
+                str(list(built.tt_ranks)).replace(" ", ""), f"{n_points:,}")
+            self.flop_per_eval = 2.0 * sum((11 + 1) * a * b for a, b in zip(built.tt_ranks[:-1], built.tt_ranks[1:]))
+            self.bytes_per_eval = 48.0
             self.kernel = "k_tt_eval_wfirst<8,3,1>"
         else:
             rng = np.random.default_rng(16)
             ranks = [1] + [16] * 9 + [1]
             cores = [rng.standard_normal((ranks[k], 11, ranks[k + 1])) / np.sqrt(ranks[k] * 11) for k in range(10)]
             self.domain = [[-1.0, 1.0]] * 10
-            self.name = "10D synthetic rank-16 ChebyshevTT eval_batch"
+            self.name = "10D synthetic rank-16 ChebyshevTT eval_batch, %s fp64 queries per GPU" % f"{n_points:,}"
             self.flop_per_eval, self.bytes_per_eval = 49920.0, 88.0
             self.kernel = "k_tt_eval_mfma<4,1,4>"
         self.d = len(cores)
@@ -168,215 +237,317 @@ class TTWork(Workload):
         self.t = self.model._dev()
 
     def points(self, rank):
-        rng = np.random.default_rng(99 + rank)
-        return np.column_stack([rng.uniform(lo, hi, self.points_per_gpu) for lo, hi in self.domain])
+        return uniform_points(self.domain, self.points_per_gpu, 99 + rank)
 
     def stream(self):
         st = ctypes.c_void_p()
-        _lib.check(self.t.lib.pcx_tt_stream(self.t.handle, ctypes.byref(st)), self.t.lib)
+        self._lib.check(self.t.lib.pcx_tt_stream(self.t.handle, ctypes.byref(st)), self.t.lib)
         return st
 
-    def launch(self, d_pts, n, d_out, stream):
-        _lib.check(self.t.lib.pcx_tt_eval_batch_dev(self.t.handle, d_pts, n, d_out, stream), self.t.lib)
+    def launch(self, d_pts, n, d_out, stream, which=None):
+        self._lib.check(self.t.lib.pcx_tt_eval_batch_dev(self.t.handle, d_pts, n, d_out, stream), self.t.lib)
 
-    def oracle_rate(self, seconds=10.0):
+    def host_eval(self, pts):
+        return [self.model.eval_batch(pts)]
+
+    def cpu_rates(self, seconds):
         import oracle
         pts = self.points(0)
-        oracle.set_num_threads(cpu_threads())
-        probe = min(len(pts), 200_000)
-        oracle.tt_eval_batch(self.cores, self.domain, pts[:20000])      # thread start-up
+
+        def c_port(threads, budget):
+            oracle.set_num_threads(threads)
+            probe = min(len(pts), 200_000)
+            oracle.tt_eval_batch(self.cores, self.domain, pts[:20000])      # thread start-up
+            t0 = time.perf_counter()
+            oracle.tt_eval_batch(self.cores, self.domain, pts[:probe])
+            rate = probe / (time.perf_counter() - t0)
+            sample = int(min(len(pts), max(probe, rate * budget)))
+            t0 = time.perf_counter()
+            oracle.tt_eval_batch(self.cores, self.domain, pts[:sample])
+            dt = time.perf_counter() - t0
+            return {"value": sample / dt, "unit": "point-evals/s", "cores": oracle.num_threads(), "kind": "port",
+                    "sample": f"first {sample} points of rank 0's batch, {dt:.1f} s"}
+
+        npn = min(len(pts), 200_000)
         t0 = time.perf_counter()
-        oracle.tt_eval_batch(self.cores, self.domain, pts[:probe])
-        rate = probe / (time.perf_counter() - t0)
-        sample = int(min(len(pts), max(probe, rate * seconds)))
-        t0 = time.perf_counter()
-        oracle.tt_eval_batch(self.cores, self.domain, pts[:sample])
-        dt = time.perf_counter() - t0
-        return sample / dt, oracle.num_threads(), f"first {sample} points of rank 0's batch, {dt:.1f} s"
+        oracle.tt_eval_batch_numpy(self.cores, self.domain, pts[:npn])
+        numpy_loop = {"value": npn / (time.perf_counter() - t0), "unit": "point-evals/s", "cores": 1,
+                      "sample": f"first {npn} points, chebval + einsum in the reference's shape "
+                                "(tensor_train.py:2252-2263), default BLAS threads"}
+        return c_port, numpy_loop
 
 
-def make_workload(name, n_points):
+def make_workload(lib_mod, name, n_points):
     if name == "bary5d":
-        return Bary5D(n_points or 1_000_000)
+        return Bary5D(lib_mod, n_points or 1_000_000, GREEK_SPECS[:1], "bary5d")
     if name == "greeks5d":
-        return Bary5D(n_points or 1_000_000, specs=F.GREEK_SPECS_5D[:6])
+        return Bary5D(lib_mod, n_points or 1_000_000, GREEK_SPECS, "greeks5d")
     if name in ("tt5d", "tt10d"):
-        return TTWork(n_points or (10_000_000 if name == "tt5d" else 4_000_000), name)
+        return TTWork(lib_mod, n_points or (10_000_000 if name == "tt5d" else 4_000_000), name)
     raise SystemExit(f"unknown workload {name}")
 
 
 # ----------------------------------------------------------------------------------
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="bary5d")
-    ap.add_argument("--points", type=int, default=0, help="query points per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-companion", action="store_true",
-                    help="bary5d only: skip the TT (config 3) measurement reported under \"tt\"")
-    ap.add_argument("--variant", type=int, default=0,
-                    help="barycentric kernel: 0 auto, 1 rows, 2 MFMA 16x16x4, 3 MFMA 4x4x4_4b")
-    args = ap.parse_args()
+# launcher: N child ranks, started before anything touches the GPU
+# ----------------------------------------------------------------------------------
+def launch_children(n: int) -> int:
+    from pychebyshev_amd import _build
+    if _build.needs_build():                 # hipcc only; no GPU call
+        _build.build()
+    base = "/dev/shm" if os.path.isdir("/dev/shm") else None
+    rdzv = tempfile.mkdtemp(prefix="pcx_rdzv_", dir=base)
+    procs = []
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       PCX_RDZV_DIR=rdzv, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+            env.setdefault("OMP_NUM_THREADS", "2")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
+        out0 = b""
+        rc = 0
+        alive = set(range(n))
+        buf = []
+        import selectors
+        sel = selectors.DefaultSelector()
+        sel.register(procs[0].stdout, selectors.EVENT_READ)
+        eof = False
+        while alive:
+            if not eof:
+                for key, _ in sel.select(timeout=0.2):
+                    chunk = os.read(key.fileobj.fileno(), 65536)
+                    if chunk:
+                        buf.append(chunk)
+                    else:
+                        eof = True
+                        sel.unregister(key.fileobj)
+            else:
+                time.sleep(0.2)
+            for r in list(alive):
+                code = procs[r].poll()
+                if code is not None:
+                    alive.discard(r)
+                    if code != 0 and rc == 0:
+                        rc = code
+                        sys.stderr.write(f"bench.py: rank {r} exited with code {code}; stopping the other ranks\n")
+                        for q in alive:       # the exact PIDs this launcher started
+                            procs[q].terminate()
+        out0 = b"".join(buf) + (procs[0].stdout.read() or b"")
+        lines = [ln for ln in out0.decode("utf-8", "replace").splitlines() if ln.strip().startswith("{")]
+        if rc == 0 and lines:
+            sys.stdout.write(lines[-1] + "\n")
+            sys.stdout.flush()
+        elif rc == 0:
+            rc = 1
+            sys.stderr.write("bench.py: rank 0 printed no JSON line\n")
+        return rc
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        shutil.rmtree(rdzv, ignore_errors=True)
 
+
+# ----------------------------------------------------------------------------------
+def run_rank(args) -> int:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
-        args.gpus = world
-    # The contract is ONE JSON line on stdout.  RCCL/torch print banners to the C-level
-    # stdout at init, so keep the real stdout aside and point fd 1 at stderr meanwhile.
+    local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
+    args.gpus = world
+    share_device = os.environ.get("PCX_BENCH_SHARE_DEVICE") == "1"      # rehearsal: every rank on GPU 0, no RCCL
+    force_comm = os.environ.get("PCX_BENCH_FORCE_COMM") == "1"          # rehearsal: RCCL + shared result with 1 rank
+    # The contract is ONE JSON line on stdout.  RCCL prints banners to the C-level stdout
+    # at init, so keep the real stdout aside and point fd 1 at stderr meanwhile.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    dist = torch = None
-    # PCX_BENCH_FORCE_TORCH=1 exercises the multi-GPU plumbing (nccl group, shared stream,
-    # gather) with a single rank, so that path can be rehearsed on a one-GPU box.
-    if world > 1 or os.environ.get("PCX_BENCH_FORCE_TORCH") == "1":
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if world == 1:
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29511")
-            os.environ.setdefault("RANK", "0")
-            os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    os.environ["PCX_DEVICE"] = str(local_rank)
-    if world == 1:
-        from pychebyshev_amd import _build
-        if _build.needs_build():          # fresh checkout: the .so is git-ignored
-            _build.build()
+    dev = 0 if share_device else local_rank
+    os.environ["PCX_DEVICE"] = str(dev)
+    from pychebyshev_amd import _build, _lib
+    from pychebyshev_amd.distributed import HostGroup, RcclComm, SharedResult, shard_table
+    if rank == 0 and _build.needs_build():    # fresh checkout: the .so is git-ignored
+        _build.build()
+    group = HostGroup.from_env(timeout=600) if (world > 1 or force_comm) else None
     lib = _lib.load()
-    dev = local_rank
+    ndev = _lib.device_count()
+    if not share_device and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} HIP device(s) visible")
 
-    def sync():
-        if torch is not None:
-            torch.cuda.synchronize()
-        else:
-            _lib.check(lib.pcx_device_synchronize(dev), lib)
+    comm, rccl_error = None, None
+    if group is not None and not share_device:
+        try:
+            comm = RcclComm(group, dev)
+        except Exception as exc:                                  # reported on the line, never silent
+            rccl_error = f"{type(exc).__name__}: {exc}"
+        flags = group.gather_floats(0.0 if comm is not None else 1.0)
+        if any(flags) and comm is not None:                       # a communicator on some ranks only is useless
+            comm.close()
+            comm = None
+            rccl_error = "RCCL initialisation failed on another rank"
+        if comm is None and rank == 0:
+            sys.stderr.write(f"bench.py: RCCL unavailable ({rccl_error}); gather falls back to shared host memory\n")
+    elif share_device and world > 1:
+        rccl_error = "PCX_BENCH_SHARE_DEVICE=1: all ranks on GPU 0, RCCL refuses duplicate devices"
+
+    def chk(rc):
+        _lib.check(rc, lib)
+
+    def dev_sync():
+        chk(lib.pcx_device_synchronize(dev))
 
     def barrier():
-        sync()
-        if dist is not None:
-            dist.barrier()
-            sync()
+        dev_sync()
+        if group is not None:
+            group.barrier()
 
-    tstream = None
-    if torch is not None:
-        # kernel and gather share one (non-default) stream, so the collective is ordered
-        # behind the kernel without a host sync; a NULL stream would mean "the handle's own".
-        tstream = torch.cuda.Stream()
-        torch.cuda.synchronize()
-        torch.cuda.set_stream(tstream)
+    live_events = []
 
-    def measure(wl, steps, warmup):
+    def new_event():
+        e = ctypes.c_void_p()
+        chk(lib.pcx_event_create(dev, ctypes.byref(e)))
+        live_events.append(e)
+        return e
+
+    def free_events():
+        for e in live_events:
+            lib.pcx_event_destroy(e)
+        live_events.clear()
+
+    def elapsed_ms(a, b):
+        ms = ctypes.c_float()
+        chk(lib.pcx_event_elapsed_ms(a, b, ctypes.byref(ms)))
+        return float(ms.value)
+
+    copy_stream = ctypes.c_void_p()
+    chk(lib.pcx_stream_create(dev, ctypes.byref(copy_stream)))
+    side_stream = comm.stream() if comm is not None else copy_stream
+
+    def measure(wl, steps, warmup, mode):
         """W untimed + K timed steps of one workload, batch resident in HBM beforehand.
-        Returns (wall seconds, max over ranks; per-step kernel milliseconds from HIP events)."""
+        mode: "none" (kernel only), "rccl" (gather of all blocks on rank 0's GPU each step),
+        "rccl+d2h" (... and rank 0 downloads the gathered result), "d2h" (every rank downloads
+        its block into the shared pinned host array).  Returns a dict; times are max over ranks."""
         n = wl.points_per_gpu
-        pts = np.ascontiguousarray(wl.points(rank))
         n_out = n * wl.evals_per_point
-        if torch is None:
-            d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
-            _lib.check(lib.pcx_dev_malloc(dev, pts.nbytes, ctypes.byref(d_pts)), lib)
-            _lib.check(lib.pcx_dev_malloc(dev, n_out * 8, ctypes.byref(d_out)), lib)
-            _lib.check(lib.pcx_memcpy_h2d(dev, d_pts, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes), lib)
-            stream = wl.stream()
-            gathered = t_out = None
-        else:
-            t_pts = torch.from_numpy(pts).cuda()
-            # two result buffers: the RCCL gather of step i (on the collective's own stream)
-            # overlaps the kernel of step i+1, which writes the other buffer
-            t_outs = [torch.empty(n_out, dtype=torch.float64, device="cuda") for _ in range(2)]
-            t_out = t_outs[0]
-            d_pts = ctypes.c_void_p(t_pts.data_ptr())
-            d_outs = [ctypes.c_void_p(t.data_ptr()) for t in t_outs]
-            stream = ctypes.c_void_p(tstream.cuda_stream)
-            gathered = [[torch.empty_like(t_out) for _ in range(world)] if rank == 0 else None
-                        for _ in range(2)]
-        pending = [None, None]
+        pts = np.ascontiguousarray(wl.points(rank))
+        d_pts = ctypes.c_void_p()
+        chk(lib.pcx_dev_malloc(dev, pts.nbytes, ctypes.byref(d_pts)))
+        chk(lib.pcx_memcpy_h2d(dev, d_pts, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes))
+        # two result buffers: the gather / download of step i (side stream) overlaps the
+        # kernel of step i+1, which writes the other buffer
+        nbuf = 1 if mode == "none" else 2
+        d_outs = []
+        for _ in range(nbuf):
+            p = ctypes.c_void_p()
+            chk(lib.pcx_dev_malloc(dev, n_out * 8, ctypes.byref(p)))
+            d_outs.append(p)
+        stream = wl.stream()
+        counts, offsets = shard_table(n * world, world, width=wl.evals_per_point)
+        d_full, shared = [], None
+        if mode in ("rccl", "rccl+d2h") and rank == 0:
+            for _ in range(nbuf):
+                p = ctypes.c_void_p()
+                chk(lib.pcx_dev_malloc(dev, n_out * world * 8, ctypes.byref(p)))
+                d_full.append(p)
+        if mode in ("d2h", "rccl+d2h"):
+            shared = SharedResult(group, n_out * world, device=dev, name="bench_" + wl.key)
+        busy = [None] * nbuf          # event: the side stream has finished with this buffer
         count = [0]
+        g_events = []
 
-        def step(events=None):
-            slot = count[0] & 1
+        def step(kev=None):
+            slot = count[0] % nbuf
             count[0] += 1
-            if dist is not None and pending[slot] is not None:
-                pending[slot].wait()          # the launch stream waits for the gather that read this buffer
-                pending[slot] = None
-            out_ptr = d_out if torch is None else d_outs[slot]
-            if events is not None:
-                _lib.check(lib.pcx_event_record(events[0], stream), lib)
-            wl.launch(d_pts, n, out_ptr, stream)
-            if events is not None:
-                _lib.check(lib.pcx_event_record(events[1], stream), lib)
-            if dist is not None:
-                # ordered behind the kernel (same current stream), not blocking the next launch
-                pending[slot] = dist.gather(t_outs[slot], gathered[slot], dst=0, async_op=True)
+            if busy[slot] is not None:
+                chk(lib.pcx_stream_wait_event(stream, busy[slot]))     # kernel must not overwrite a block in flight
+            if kev is not None:
+                chk(lib.pcx_event_record(kev[0], stream))
+            wl.launch(d_pts, n, d_outs[slot], stream)
+            if kev is not None:
+                chk(lib.pcx_event_record(kev[1], stream))
+            if mode == "none":
+                return
+            done = kev[1] if kev is not None else new_event()
+            if kev is None:
+                chk(lib.pcx_event_record(done, stream))
+            chk(lib.pcx_stream_wait_event(side_stream, done))
+            g0 = g1 = None
+            if kev is not None:
+                g0, g1 = new_event(), new_event()
+                chk(lib.pcx_event_record(g0, side_stream))
+            if mode in ("rccl", "rccl+d2h"):
+                comm.gatherv_dev(d_outs[slot], d_full[slot] if rank == 0 else None, counts, offsets, 0, side_stream)
+                if mode == "rccl+d2h" and rank == 0:
+                    chk(lib.pcx_memcpy_d2h_async(ctypes.c_void_p(shared.address(0)), d_full[slot],
+                                                 n_out * world * 8, side_stream))
+            else:
+                chk(lib.pcx_memcpy_d2h_async(ctypes.c_void_p(shared.address(int(offsets[rank]))), d_outs[slot],
+                                             n_out * 8, side_stream))
+            ev = new_event()
+            chk(lib.pcx_event_record(ev, side_stream))
+            if kev is not None:
+                g1 = ev
+                g_events.append((g0, g1))
+            busy[slot] = ev
 
-        def drain():
-            for i in (0, 1):
-                if pending[i] is not None:
-                    pending[i].wait()
-                    pending[i] = None
-
-        evs = []
-        for _ in range(steps):
-            a, b = ctypes.c_void_p(), ctypes.c_void_p()
-            _lib.check(lib.pcx_event_create(dev, ctypes.byref(a)), lib)
-            _lib.check(lib.pcx_event_create(dev, ctypes.byref(b)), lib)
-            evs.append((a, b))
+        kevs = [(new_event(), new_event()) for _ in range(steps)]
         for _ in range(warmup):
             step()
-        drain()
         barrier()
         t0 = time.perf_counter()
         for i in range(steps):
-            step(evs[i])
-        drain()                               # every gather of the K timed steps has completed
-        barrier()
+            step(kevs[i])
+        barrier()                              # device sync: every kernel, gather and download has completed
         elapsed = time.perf_counter() - t0
-
-        kernel_ms = []
-        for a, b in evs:
-            ms = ctypes.c_float()
-            _lib.check(lib.pcx_event_elapsed_ms(a, b, ctypes.byref(ms)), lib)
-            kernel_ms.append(ms.value)
-            lib.pcx_event_destroy(a)
-            lib.pcx_event_destroy(b)
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        # sanity: the last step's results are finite
-        if torch is None:
-            got = np.empty(n_out)
-            _lib.check(lib.pcx_memcpy_d2h(dev, got.ctypes.data_as(ctypes.c_void_p), d_out, n_out * 8), lib)
-            lib.pcx_dev_free(dev, d_pts)
-            lib.pcx_dev_free(dev, d_out)
-        else:
-            got = t_outs[(count[0] - 1) & 1].cpu().numpy()
+        elapsed = group.max(elapsed) if group is not None else elapsed
+        kernel_ms = [elapsed_ms(a, b) for a, b in kevs]
+        gather_ms = [elapsed_ms(a, b) for a, b in g_events]
+        # sanity: the last step's results are finite (and, gathered, complete)
+        got = np.empty(n_out)
+        chk(lib.pcx_memcpy_d2h(dev, got.ctypes.data_as(ctypes.c_void_p), d_outs[(count[0] - 1) % nbuf], n_out * 8))
         if not np.isfinite(got).all():
             raise SystemExit(f"non-finite results in the benchmark batch ({wl.name})")
-        return elapsed, kernel_ms
+        if rank == 0 and mode in ("rccl", "rccl+d2h"):
+            full = np.empty(n_out * world)
+            chk(lib.pcx_memcpy_d2h(dev, full.ctypes.data_as(ctypes.c_void_p), d_full[(count[0] - 1) % nbuf],
+                                   full.nbytes))
+            if not (np.isfinite(full).all() and np.array_equal(full[:n_out], got)):
+                raise SystemExit("gathered result does not contain rank 0's block")
+        if shared is not None and rank == 0:
+            host = np.array(shared.array, copy=True)
+            if not (np.isfinite(host).all() and np.array_equal(host[:n_out], got)):
+                raise SystemExit("shared host result does not contain rank 0's block")
+        pinned = shared.pinned if shared is not None else None
+        if shared is not None:
+            shared.close()
+        for p in [d_pts] + d_outs + d_full:
+            lib.pcx_dev_free(dev, p)
+        free_events()
+        launches = wl.evals_per_point
+        avg_launch = float(np.mean(kernel_ms)) / launches
+        rec = {"elapsed": elapsed, "kernel_ms": kernel_ms, "avg_launch_ms": avg_launch,
+               "avg_launch_ms_per_rank": group.gather_floats(avg_launch) if group is not None else [avg_launch],
+               "side_ms": float(np.mean(gather_ms)) if gather_ms else None, "pinned": pinned}
+        return rec
 
-    def roofline_of(wl, kernel_ms, workload_key):
+    def rate(wl, rec, steps):
+        return float(wl.points_per_gpu) * wl.evals_per_point * world * steps / rec["elapsed"]
+
+    def roofline_of(wl, rec):
         n = wl.points_per_gpu
-        launches = wl.evals_per_point                     # kernel launches between the two events
-        avg_launch_s = float(np.mean(kernel_ms)) / 1e3 / launches
+        avg_launch_s = rec["avg_launch_ms"] / 1e3
         flop_per_launch = wl.flop_per_eval * n
         achieved = flop_per_launch / avg_launch_s / 1e12
-        traffic = None
+        traffic, source = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             try:
-                rec = json.load(open(pmc_path)).get(workload_key)
-                if rec and rec.get("points") == n:
-                    traffic = rec["hbm_bytes_per_launch"]
+                r = json.load(open(pmc_path)).get(wl.key)
+                if r and r.get("points") == n:
+                    traffic = r["hbm_bytes_per_launch"]
+                    source = f"cached PMC (not collected in this run): {r.get('source')}"
             except Exception:
                 traffic = None
         return {"bound": "mfma", "kernel": wl.kernel, "achieved": achieved,
@@ -386,38 +557,126 @@ def main():
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_hbm_bytes_per_launch": wl.bytes_per_eval * n,
                 "hbm_frac": wl.bytes_per_eval * n / avg_launch_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic}
+                "traffic": traffic, "traffic_source": source}
 
-    wl = make_workload(args.workload, args.points)
+    def end_to_end(wl, reps=3):
+        """Host-pointer entry point on rank 0's batch: pageable NumPy in, NumPy out."""
+        pts = np.ascontiguousarray(wl.points(rank))
+        wl.host_eval(pts[: min(len(pts), 65536)])                  # staging buffers, derivative tensors
+        wl.host_eval(pts)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            wl.host_eval(pts)
+        dt = (time.perf_counter() - t0) / reps
+        return {"value": len(pts) * wl.evals_per_point / dt, "unit": "point-evals/s", "ms_per_call": dt * 1e3,
+                "what": "host-pointer C-ABI call on the same batch: pageable H2D + kernel + D2H inclusive"}
+
+    def cpu_baseline(wl, seconds):
+        c_port, numpy_loop = wl.cpu_rates(seconds)
+        cores = int(os.environ.get("PCX_CPU_THREADS", "0")) or usable_cores()
+        rec = c_port(cores, seconds)
+        rec["host_cpus"] = os.cpu_count()
+        rec["cores_note"] = ("all host cores this process may use: min(CPU affinity %d, cgroup cpu.max quota) = %d"
+                             % (len(os.sched_getaffinity(0)), usable_cores()))
+        if cores > 16:
+            share = c_port(16, min(seconds, 4.0))
+            rec["per_gpu_cpu_share"] = {k: share[k] for k in ("value", "unit", "cores", "sample")}
+        rec["numpy_loop"] = numpy_loop
+        return rec
+
+    def gather_report(wl, steps, warmup, headline):
+        """The same K steps under every way of collecting the result blocks."""
+        out = {}
+        modes = [("none", "no gather (kernel launches only)")]
+        if comm is not None:
+            modes += [("rccl", "RCCL gather on rank 0's GPU each step, overlapping the next launch"),
+                      ("rccl+d2h", "RCCL gather, then rank 0 downloads the full result to pinned host memory")]
+        modes += [("d2h", "no collective: every rank downloads its block into one pinned shared-memory array")]
+        for mode, what in modes:
+            rec = headline if mode == headline_mode else measure(wl, steps, warmup, mode)
+            out[mode] = {"what": what, "value": rate(wl, rec, steps), "ms_per_step": rec["elapsed"] / steps * 1e3,
+                         "side_stream_ms_per_step": rec["side_ms"]}
+            if rec["pinned"] is not None:
+                out[mode]["host_buffer_pinned"] = rec["pinned"]
+        return out
+
+    multi = group is not None
+    headline_mode = "none" if not multi else ("rccl" if comm is not None else "d2h")
+    if args.gather != "auto":
+        if args.gather in ("rccl", "rccl+d2h") and comm is None:
+            raise SystemExit(f"--gather {args.gather} needs RCCL: {rccl_error}")
+        if args.gather != "none" and not multi:
+            raise SystemExit("--gather needs more than one rank (or PCX_BENCH_FORCE_COMM=1)")
+        headline_mode = args.gather
+
+    wl = make_workload(_lib, args.workload, args.points)
     if args.variant and hasattr(wl, "m"):
-        _lib.check(wl.m.lib.pcx_bary_set_kernel(wl.m.handle, args.variant), wl.m.lib)
+        chk(wl.m.lib.pcx_bary_set_kernel(wl.m.handle, args.variant))
     n = wl.points_per_gpu
-    elapsed, kernel_ms = measure(wl, args.steps, args.warmup)
+    head = measure(wl, args.steps, args.warmup, headline_mode)
+    gathers = gather_report(wl, args.steps, args.warmup, head) if multi else None
 
-    # the metric names both interpolants: the default (barycentric) run also times the TT
-    # half of it -- config 3's eval_batch, 10^7 points per GPU -- and reports it beside the
-    # headline value (same timing discipline, same JSON line, never mixed into `value`)
-    companion = None
+    def companion(name):
+        cwl = make_workload(_lib, name, 0)
+        rec = measure(cwl, args.steps, args.warmup, headline_mode)
+        if rank != 0:
+            return None
+        out = {"workload": cwl.name, "points_per_gpu_per_step": cwl.points_per_gpu,
+               "evals_per_point": cwl.evals_per_point, "value": rate(cwl, rec, args.steps),
+               "unit": "point-evals/s", "ms_per_step": rec["elapsed"] / args.steps * 1e3,
+               "roofline": roofline_of(cwl, rec)}
+        if cwl.build_info:
+            out["build"] = cwl.build_info
+        return out, cwl
+
+    # the metric names both interpolants and BASELINE.json lists the Greeks run as a config:
+    # the default (barycentric) run also times config 3 (TT) and config 4 (Greeks) with the
+    # same discipline and reports them beside the headline value, never mixed into it
+    companions = {}
     if args.workload == "bary5d" and not args.no_companion:
-        cwl = make_workload("tt5d", 0)
-        c_elapsed, c_ms = measure(cwl, args.steps, args.warmup)
-        if rank == 0:
-            companion = {"workload": cwl.name, "build": cwl.build_info, "points_per_gpu_per_step": cwl.points_per_gpu,
-                         "value": float(cwl.points_per_gpu) * world * args.steps / c_elapsed,
-                         "unit": "point-evals/s", "ms_per_step": c_elapsed / args.steps * 1e3,
-                         "roofline": roofline_of(cwl, c_ms, "tt5d")}
+        for name, field in (("greeks5d", "greeks"), ("tt5d", "tt")):
+            got = companion(name)
+            if got is None:
+                continue
+            out, cwl = got
+            if name == "greeks5d":
+                # per-spec rates from separate single-spec launches (events around each launch)
+                per = {}
+                if world == 1:
+                    pts = np.ascontiguousarray(cwl.points(rank))
+                    d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+                    chk(lib.pcx_dev_malloc(dev, pts.nbytes, ctypes.byref(d_pts)))
+                    chk(lib.pcx_dev_malloc(dev, cwl.points_per_gpu * 6 * 8, ctypes.byref(d_out)))
+                    chk(lib.pcx_memcpy_h2d(dev, d_pts, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes))
+                    st = cwl.stream()
+                    for i, nm in enumerate(GREEK_NAMES):
+                        a, b = new_event(), new_event()
+                        cwl.launch(d_pts, cwl.points_per_gpu, d_out, st, which=i)
+                        chk(lib.pcx_event_record(a, st))
+                        for _ in range(5):
+                            cwl.launch(d_pts, cwl.points_per_gpu, d_out, st, which=i)
+                        chk(lib.pcx_event_record(b, st))
+                        per[nm] = cwl.points_per_gpu * 5 / (elapsed_ms(a, b) / 1e3)
+                    lib.pcx_dev_free(dev, d_pts)
+                    lib.pcx_dev_free(dev, d_out)
+                    free_events()
+                    out["per_spec_point_evals_per_s"] = per
+                    out["specs"] = GREEK_SPECS
+            if world == 1 and not args.no_cpu_baseline:
+                if name == "tt5d":
+                    out["cpu_baseline"] = cpu_baseline(cwl, 6.0)
+                out["end_to_end"] = end_to_end(cwl, reps=2)
+            companions[field] = out
 
     if rank == 0:
-        total_evals = float(n) * wl.evals_per_point * world * args.steps
-        value = total_evals / elapsed
         line = {
-            "metric": "point-evals/sec, 5D Black-Scholes n=11^5 barycentric + TT, 1/2/4/8 GPU",
-            "value": value,
+            "metric": METRIC,
+            "value": rate(wl, head, args.steps),
             "unit": "point-evals/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step": head["elapsed"] / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -425,28 +684,62 @@ def main():
             "data": "synthetic",
             "config": {"workload": wl.name, "points_per_gpu_per_step": n,
                        "evals_per_point": wl.evals_per_point,
-                       "parallelism": f"batch-sharded x{world}, model replicated"
-                                      + (", RCCL gather of results each step (overlapping the next launch)" if dist is not None else "")},
-            "roofline": roofline_of(wl, kernel_ms, args.workload),
+                       "parallelism": f"batch-sharded x{world}, model replicated, one process per GPU"
+                                      + {"none": "", "rccl": ", RCCL gather of the result blocks on rank 0 each step "
+                                                             "(overlapping the next launch)",
+                                         "rccl+d2h": ", RCCL gather + download on rank 0 each step",
+                                         "d2h": ", every rank downloads its block into shared pinned host memory "
+                                                "each step"}[headline_mode],
+                       "gather": headline_mode},
+            "roofline": roofline_of(wl, head),
         }
-        if getattr(wl, "build_info", None):
+        line["roofline"]["avg_launch_ms_per_rank"] = head["avg_launch_ms_per_rank"]
+        if wl.build_info:
             line["config"]["build"] = wl.build_info
-        if companion is not None:
-            line["tt"] = companion
-        if world == 1 and not args.no_cpu_baseline:
-            rate, cores, sample = wl.oracle_rate()
-            line["cpu_baseline"] = {"value": rate, "unit": "point-evals/s", "cores": cores,
-                                    "kind": "port", "sample": sample,
-                                    "host_cpus": os.cpu_count()}
-            if getattr(wl, "numpy_loop", None):
-                line["cpu_baseline"]["numpy_loop"] = wl.numpy_loop
+        if multi:
+            line["gather"] = gathers
+            line["comm"] = {"backend": "rccl" if comm is not None else None,
+                            "rccl_version": comm.rccl_version if comm is not None else None,
+                            "rccl_error": rccl_error, "torch": "torch" in sys.modules}
+        line.update(companions)
+    if world == 1 and not args.no_cpu_baseline:
+        e2e = end_to_end(wl)
+        cpu = cpu_baseline(wl, 10.0)
+        if rank == 0:
+            line["end_to_end"] = e2e
+            line["cpu_baseline"] = cpu
+    if rank == 0:
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
 
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    lib.pcx_stream_destroy(copy_stream)
+    if comm is not None:
+        comm.close()
+    if group is not None:
+        group.close()
+    return 0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="bary5d", choices=["bary5d", "greeks5d", "tt5d", "tt10d"])
+    ap.add_argument("--points", type=int, default=0, help="query points per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the CPU baseline and the host-pointer end_to_end legs")
+    ap.add_argument("--no-companion", action="store_true",
+                    help="bary5d only: skip the Greeks (config 4) and TT (config 3) companions")
+    ap.add_argument("--gather", default="auto", choices=["auto", "none", "rccl", "rccl+d2h", "d2h"],
+                    help="what each timed step of the headline does with the result blocks (N > 1)")
+    ap.add_argument("--variant", type=int, default=0,
+                    help="barycentric kernel: 0 auto, 1 rows, 2 MFMA 16x16x4, 3 MFMA 4x4x4_4b")
+    args = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return launch_children(args.gpus)
+    return run_rank(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

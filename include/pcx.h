@@ -65,6 +65,19 @@ int pcx_event_create(int device, void **event);
 int pcx_event_record(void *event, void *stream);
 int pcx_event_elapsed_ms(void *start, void *stop, float *ms); /* synchronizes on `stop` */
 int pcx_event_destroy(void *event);
+/* Streams and asynchronous copies for drivers that overlap the gather / download of one
+ * step with the kernel of the next (bench.py, pychebyshev_amd/distributed.py).  A stream
+ * belongs to the device it was created on.  pcx_host_register pins an existing host range
+ * (e.g. a POSIX shared-memory result buffer every rank downloads its block into) so that
+ * device-to-host copies into it run at full PCIe rate and asynchronously.               */
+int pcx_stream_create(int device, void **stream);
+int pcx_stream_destroy(void *stream);
+int pcx_stream_synchronize(void *stream);
+int pcx_stream_wait_event(void *stream, void *event);
+int pcx_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *stream);
+int pcx_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream);
+int pcx_host_register(int device, void *ptr, size_t bytes);
+int pcx_host_unregister(void *ptr);
 
 /* ---- barycentric full-tensor interpolant ----------------------------------- */
 /* State of ChebyshevApproximation (barycentric.py:401-414): per-dimension nodes,
@@ -185,6 +198,37 @@ int pcx_tt_grid_eval(int device, int d, const int32_t *n_nodes, const int32_t *r
 int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const double *tensor, int max_rank,
                double tol, int32_t *ranks_out, double *cores_out, int64_t cores_cap,
                int64_t *cores_len, int32_t *sweeps_out);
+
+/* ---- multi-GPU: the final gather of the per-rank result blocks ----------------- */
+/* The reference has no multi-device path (docs/roadmap.md:245); SURVEY.md 8(e) defines
+ * it: query rows are sharded in contiguous blocks over one process per GPU, the model is
+ * replicated, and the ONLY exchange is the gather of the result blocks on one rank --
+ * here grouped ncclSend/ncclRecv of RCCL over xGMI (one direct link per peer, no ring).
+ * RCCL (librccl.so.1 of the ROCm this library was built with) is dlopen'ed on the first
+ * pcx_comm_* call: single-GPU users never load it.  No PyTorch anywhere.
+ *
+ * Bootstrap: rank 0 calls pcx_comm_unique_id and hands the PCX_COMM_ID_BYTES opaque bytes
+ * to the other ranks by any host channel (pychebyshev_amd.distributed.HostGroup uses a
+ * shared-memory file); every rank then calls pcx_comm_create (collective, blocking).      */
+#define PCX_COMM_ID_BYTES 128
+typedef struct pcx_comm pcx_comm;
+int pcx_comm_unique_id(void *id_out /* PCX_COMM_ID_BYTES */);
+int pcx_comm_create(int device, int rank, int world, const void *id, pcx_comm **out);
+int pcx_comm_destroy(pcx_comm *c);
+/* rank, world, device, RCCL version code (any pointer may be NULL)                      */
+int pcx_comm_info(pcx_comm *c, int32_t *rank, int32_t *world, int32_t *device, int32_t *rccl_version);
+/* Gather blocks of doubles on `root`: rank r contributes counts[r] doubles from d_send,
+ * which land at d_recv + offsets[r] on root (d_recv is ignored elsewhere; counts/offsets
+ * have `world` entries and must be identical on every rank).  Enqueues on `stream`
+ * (NULL = the communicator's own stream) and returns without synchronizing: ordered
+ * behind the kernel that produced d_send when that ran on the same stream.              */
+int pcx_comm_gatherv_dev(pcx_comm *c, const double *d_send, double *d_recv, const int64_t *counts,
+                         const int64_t *offsets, int root, void *stream);
+/* Host-level helpers for drivers: max over ranks of one double (the benchmark's
+ * max-over-ranks step time) and a barrier; both synchronize the communicator's stream.  */
+int pcx_comm_allreduce_max(pcx_comm *c, double *value_inout);
+int pcx_comm_barrier(pcx_comm *c);
+int pcx_comm_stream(pcx_comm *c, void **stream);
 
 #ifdef __cplusplus
 }

@@ -206,6 +206,25 @@ def tt_eval_batch(coeff_cores, domain, pts, dim_order=None) -> np.ndarray:
     return out
 
 
+def tt_eval_batch_numpy(coeff_cores, domain, pts, dim_order=None) -> np.ndarray:
+    """The reference's eval_batch in its own shape (tensor_train.py:2242-2265): per
+    dimension ``chebval(scaled, eye(n))`` (NumPy Clenshaw on identity coefficients) and two
+    einsums that materialise (N, r, r') temporaries.  The "NumPy CPU path" TT baseline and
+    a second oracle for the C restatement's forward recurrence."""
+    pts = np.asarray(pts)
+    d = len(coeff_cores)
+    if dim_order is not None and list(dim_order) != list(range(d)):
+        pts = pts[:, list(dim_order)]
+    result = np.ones((pts.shape[0], 1, 1))
+    for k in range(d):
+        a, b = domain[k]
+        scaled = 2.0 * (pts[:, k] - a) / (b - a) - 1.0
+        q = np.polynomial.chebyshev.chebval(scaled, np.eye(coeff_cores[k].shape[1])).T
+        v = np.einsum("nj,ijk->nik", q, coeff_cores[k])
+        result = np.einsum("nij,njk->nik", result, v)
+    return result[:, 0, 0]
+
+
 def value_to_coeff_core(core) -> np.ndarray:
     core = _f64(core)
     rl, n, rr = core.shape

@@ -15,10 +15,16 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpcx_hip.so")
-SOURCES = ["pcx_api.hip"]
-HEADERS = ["pcx_common.h", "bary_kernels.h", "tt_kernels.h", "ttcross_kernels.h", "ttsvd_kernels.h",
-           os.path.join("..", "..", "include", "pcx.h")]
+# translation unit -> headers it includes (an object is rebuilt when any of them is newer)
+PCX_H = os.path.join("..", "..", "include", "pcx.h")
+SOURCES = {
+    "pcx_api.hip": ["pcx_common.h", "bary_kernels.h", "tt_kernels.h", "ttcross_kernels.h", "ttsvd_kernels.h",
+                    PCX_H],
+    "pcx_comm.hip": [PCX_H],
+}
+OBJ_DIR = os.path.join(HERE, "_obj")
 ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-fno-fast-math", "-ffp-contract=on", "-Wall", "-Wno-unused-function"]
 
 
 def hipcc_path() -> str:
@@ -28,27 +34,45 @@ def hipcc_path() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB):
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    files = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.abspath(__file__)]
-    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in files)
+    t = os.path.getmtime(target)
+    return any(os.path.exists(f) and os.path.getmtime(f) > t for f in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
-        return LIB
-    cmd = [hipcc_path(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-fast-math", "-ffp-contract=on", "-Wall", "-Wno-unused-function",
-           "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+def _deps(src: str):
+    return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in SOURCES[src]] + [os.path.abspath(__file__)]
+
+
+def needs_build() -> bool:
+    return any(_newer(LIB, _deps(src)) for src in SOURCES)
+
+
+def _run(cmd, verbose):
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout)
     if verbose and res.stdout.strip():
         print(res.stdout)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile each translation unit to pychebyshev_amd/_obj/*.o (only the stale ones) and
+    link libpcx_hip.so.  RCCL is not linked: pcx_comm.hip dlopen's it on first use."""
+    if not force and not needs_build():
+        return LIB
+    hipcc = hipcc_path()
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if force or _newer(obj, _deps(src)):
+            _run([hipcc, f"--offload-arch={ARCH}", "-c"] + FLAGS + ["-o", obj, os.path.join(CSRC, src)], verbose)
+    _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], verbose)
     return LIB
 
 

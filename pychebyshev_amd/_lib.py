@@ -59,6 +59,14 @@ SIGNATURES = {
     "pcx_event_record": (_I, [_V, _V]),
     "pcx_event_elapsed_ms": (_I, [_V, _V, ctypes.POINTER(ctypes.c_float)]),
     "pcx_event_destroy": (_I, [_V]),
+    "pcx_stream_create": (_I, [_I, c_vpp]),
+    "pcx_stream_destroy": (_I, [_V]),
+    "pcx_stream_synchronize": (_I, [_V]),
+    "pcx_stream_wait_event": (_I, [_V, _V]),
+    "pcx_memcpy_h2d_async": (_I, [_V, _V, _Z, _V]),
+    "pcx_memcpy_d2h_async": (_I, [_V, _V, _Z, _V]),
+    "pcx_host_register": (_I, [_I, _V, _Z]),
+    "pcx_host_unregister": (_I, [_V]),
     "pcx_bary_create": (_I, [_I, _I, c_i32p, c_f64p, c_f64p, c_f64p, c_f64p, c_vpp]),
     "pcx_bary_destroy": (_I, [_V]),
     "pcx_bary_create_from_pcb": (_I, [_I, ctypes.c_char_p, c_vpp]),
@@ -87,6 +95,14 @@ SIGNATURES = {
     "pcx_tt_value_to_coeff_core": (_I, [_I, c_f64p, _I, _I, _I, c_f64p]),
     "pcx_tt_grid_eval": (_I, [_I, _I, c_i32p, c_i32p, c_f64p, c_i32p, _I, c_f64p]),
     "pcx_tt_svd": (_I, [_I, _I, c_i32p, c_f64p, _I, _D, c_i32p, c_f64p, _L, c_i64p, c_i32p]),
+    "pcx_comm_unique_id": (_I, [_V]),
+    "pcx_comm_create": (_I, [_I, _I, _I, _V, c_vpp]),
+    "pcx_comm_destroy": (_I, [_V]),
+    "pcx_comm_info": (_I, [_V, c_i32p, c_i32p, c_i32p, c_i32p]),
+    "pcx_comm_gatherv_dev": (_I, [_V, _V, _V, c_i64p, c_i64p, _I, _V]),
+    "pcx_comm_allreduce_max": (_I, [_V, ctypes.POINTER(_D)]),
+    "pcx_comm_barrier": (_I, [_V]),
+    "pcx_comm_stream": (_I, [_V, c_vpp]),
 }
 
 _LIB = None

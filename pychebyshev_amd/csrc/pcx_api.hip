@@ -32,6 +32,12 @@ static int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+// the other translation units of the library (pcx_comm.hip) report through the same buffer
+__attribute__((visibility("hidden"))) int pcx_fail_v(int code, const char *fmt, va_list ap) {
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    return code;
+}
+
 #define HIP_TRY(expr)                                                                      \
     do {                                                                                   \
         hipError_t e_ = (expr);                                                            \
@@ -127,6 +133,49 @@ extern "C" int pcx_event_elapsed_ms(void *start, void *stop, float *ms) {
 }
 extern "C" int pcx_event_destroy(void *event) {
     if (event) HIP_TRY(hipEventDestroy((hipEvent_t)event));
+    return PCX_OK;
+}
+extern "C" int pcx_stream_create(int device, void **stream) {
+    if (!stream) return fail(PCX_ERR_INVALID, "stream is NULL");
+    int rc = use_device(device);
+    if (rc) return rc;
+    hipStream_t st;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *stream = (void *)st;
+    return PCX_OK;
+}
+extern "C" int pcx_stream_destroy(void *stream) {
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return PCX_OK;
+}
+extern "C" int pcx_stream_synchronize(void *stream) {
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return PCX_OK;
+}
+extern "C" int pcx_stream_wait_event(void *stream, void *event) {
+    if (!event) return fail(PCX_ERR_INVALID, "event is NULL");
+    HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)event, 0));
+    return PCX_OK;
+}
+extern "C" int pcx_memcpy_h2d_async(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes && (!dst || !src)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return PCX_OK;
+}
+extern "C" int pcx_memcpy_d2h_async(void *dst, const void *src, size_t bytes, void *stream) {
+    if (bytes && (!dst || !src)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PCX_OK;
+}
+extern "C" int pcx_host_register(int device, void *ptr, size_t bytes) {
+    if (!ptr || !bytes) return fail(PCX_ERR_INVALID, "empty host range");
+    int rc = use_device(device);
+    if (rc) return rc;
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterPortable));
+    return PCX_OK;
+}
+extern "C" int pcx_host_unregister(void *ptr) {
+    if (ptr) HIP_TRY(hipHostUnregister(ptr));
     return PCX_OK;
 }
 

@@ -1,14 +1,30 @@
-"""Sharding of query batches across the GPUs of one node (one process per GPU).
+"""Sharding of query batches across the GPUs of one node -- one process per GPU, no PyTorch.
 
-The path has no exchange step: every query point is independent and the model (<= 1.3 MB)
-is replicated, so rank g evaluates a contiguous row block of ``points`` on its own GPU.
-The only collective is the final gather of the per-rank result blocks
-(``torch.distributed`` -- RCCL over xGMI with the ``nccl`` backend, ``gloo`` on CPU for
-tests).  ``torch`` is imported lazily and only here: it is launch/collective plumbing.
+The path has no exchange step (the reference itself is single-process,
+``docs/roadmap.md:245``): every query point is independent and the model (<= 1.3 MB) is
+replicated, so rank g evaluates a contiguous row block of ``points`` on its own GPU.  What
+is left is getting the result blocks into one place.  Two ways, both here:
+
+* :class:`RcclComm` -- the gather on RCCL over xGMI (``pcx_comm_*`` of the C ABI: grouped
+  ``ncclSend``/``ncclRecv``, one direct link per peer), result on rank 0's GPU;
+* :class:`SharedResult` -- every rank copies its block device-to-host straight into its
+  slice of one POSIX shared-memory result array (G parallel PCIe copies, no collective).
+
+:class:`HostGroup` is the host-side rendezvous both need (ranks, barrier, small blobs such
+as the RCCL unique id, max-over-ranks).  It is a file in ``/dev/shm`` with one
+single-writer slot per rank -- it works without a GPU, which is how the world-size-2 CPU
+tests drive this module.  Environment: ``RANK`` / ``LOCAL_RANK`` / ``WORLD_SIZE`` as set by
+``torch.distributed.run`` (used as a plain process launcher) or by ``bench.py``'s own
+launcher; ``PCX_RDZV_DIR`` names the rendezvous directory explicitly.
 """
 from __future__ import annotations
 
-from typing import Callable, Tuple
+import ctypes
+import mmap
+import os
+import struct
+import time
+from typing import Callable, Optional, Tuple
 
 import numpy as np
 
@@ -22,44 +38,279 @@ def shard_bounds(n_rows: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, min(n_rows, lo + per)
 
 
-def gather_results(local: "np.ndarray", n_rows: int, group=None, dst: int = 0):
-    """Gather per-rank result blocks (layout of :func:`shard_bounds`) on rank ``dst``.
-
-    ``local`` may be a NumPy array (CPU / gloo) or a torch tensor already on this rank's
-    GPU (nccl = RCCL).  Returns the full ``(n_rows,)`` array on ``dst`` and ``None`` elsewhere.
-    """
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    rank = dist.get_rank(group)
-    per = -(-n_rows // world)
-    is_np = isinstance(local, np.ndarray)
-    t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local
-    if dist.get_backend(group) == "nccl" and t.device.type == "cpu":
-        t = t.cuda()                        # RCCL moves device memory: stage the host block on this rank's GPU
-    buf = torch.zeros(per, dtype=t.dtype, device=t.device)   # equal-size blocks for gather
-    buf[: t.numel()] = t
-    if dist.get_backend(group) == "nccl":
-        out = torch.empty(per * world, dtype=t.dtype, device=t.device) if rank == dst else None
-        outs = list(out.split(per)) if rank == dst else None
-        dist.gather(buf, outs, dst=dst, group=group)
-    else:
-        outs = [torch.empty_like(buf) for _ in range(world)] if rank == dst else None
-        dist.gather(buf, outs, dst=dst, group=group)
-        out = torch.cat(outs) if rank == dst else None
-    if rank != dst:
-        return None
-    full = out[:n_rows]
-    return full.cpu().numpy() if is_np else full
+def shard_table(n_rows: int, world_size: int, width: int = 1):
+    """(counts, offsets) in elements of every rank's block, ``width`` values per row."""
+    b = [shard_bounds(n_rows, r, world_size) for r in range(world_size)]
+    counts = np.array([(hi - lo) * width for lo, hi in b], dtype=np.int64)
+    offsets = np.array([lo * width for lo, _ in b], dtype=np.int64)
+    return counts, offsets
 
 
-def eval_sharded(evaluate: Callable[["np.ndarray"], "np.ndarray"], points: "np.ndarray", group=None,
-                 dst: int = 0):
-    """Evaluate ``points`` (same array on every rank) block-wise: each rank runs
-    ``evaluate`` on its own row block; results are gathered on ``dst``."""
-    import torch.distributed as dist
+# --------------------------------------------------------------------------------------
+# host rendezvous
+# --------------------------------------------------------------------------------------
+_MAGIC = 0x5043584752503031          # "PCXGRP01"
+_HDR = 64                            # magic, world, created_ns
+_SLOT = 512                          # gen (i64), blob length (i64), blob (<= 496 bytes)
+_BLOB_MAX = _SLOT - 16
 
-    lo, hi = shard_bounds(points.shape[0], dist.get_rank(group), dist.get_world_size(group))
-    local = np.asarray(evaluate(points[lo:hi]), dtype=np.float64)
-    return gather_results(local, points.shape[0], group=group, dst=dst)
+
+class HostGroup:
+    """Ranks of one node meeting in a shared-memory file: one slot per rank, written only
+    by its owner (generation counter + a small blob), read by everyone.  ``barrier``,
+    ``allgather_bytes``, ``broadcast_bytes``, ``max``.  Spin-waits with short sleeps; every
+    wait has a timeout (a missing rank raises instead of hanging)."""
+
+    def __init__(self, rank: int, world: int, directory: str, timeout: float = 300.0):
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError(f"bad rank/world {rank}/{world}")
+        self.rank, self.world, self.timeout = rank, world, timeout
+        self.directory = directory
+        self.path = os.path.join(directory, "group.bin")
+        self._gen = 0
+        size = _HDR + world * _SLOT
+        if rank == 0:
+            os.makedirs(directory, exist_ok=True)
+            try:
+                os.unlink(self.path)                     # leftovers of a crashed run with the same key
+            except FileNotFoundError:
+                pass
+            tmp = self.path + f".{os.getpid()}.tmp"
+            with open(tmp, "wb") as f:
+                f.write(struct.pack("<qqq", _MAGIC, world, time.time_ns()).ljust(_HDR, b"\0"))
+                f.write(b"\0" * (world * _SLOT))
+            os.rename(tmp, self.path)                    # appears complete or not at all
+        deadline = time.monotonic() + timeout
+        while True:
+            try:
+                fd = os.open(self.path, os.O_RDWR)
+                try:
+                    if os.fstat(fd).st_size == size:
+                        head = os.pread(fd, 24, 0)
+                        magic, w, created = struct.unpack("<qqq", head)
+                        fresh = abs(time.time_ns() - created) < 900e9
+                        if magic == _MAGIC and w == world and fresh:
+                            self._mm = mmap.mmap(fd, size)
+                            break
+                finally:
+                    os.close(fd)
+            except FileNotFoundError:
+                pass
+            if time.monotonic() > deadline:
+                raise TimeoutError(f"rank {rank}: no rendezvous file {self.path} from rank 0")
+            time.sleep(0.002)
+        self._gens = np.frombuffer(self._mm, dtype=np.int64, count=world * (_SLOT // 8),
+                                   offset=_HDR)[:: _SLOT // 8]
+        self.barrier()
+
+    # -- construction from the launcher's environment ---------------------------------
+    @classmethod
+    def from_env(cls, timeout: float = 300.0) -> "HostGroup":
+        rank = int(os.environ.get("RANK", "0"))
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        d = os.environ.get("PCX_RDZV_DIR")
+        if not d:
+            # ranks of one launch share their parent (the launcher) and its master port
+            key = "%d_%s_%s" % (os.getppid(), os.environ.get("MASTER_PORT", "0"),
+                                os.environ.get("TORCHELASTIC_RESTART_COUNT", "0"))
+            base = "/dev/shm" if os.path.isdir("/dev/shm") else "/tmp"
+            d = os.path.join(base, f"pcx_rdzv_{os.getuid()}_{key}")
+        return cls(rank, world, d, timeout)
+
+    # -- primitives -------------------------------------------------------------------
+    def _slot(self, r: int) -> int:
+        return _HDR + r * _SLOT
+
+    def _wait_all(self, gen: int):
+        deadline = time.monotonic() + self.timeout
+        spins = 0
+        while True:
+            if int(self._gens.min()) >= gen:
+                return
+            spins += 1
+            if spins > 200:
+                time.sleep(0.0002)
+                if time.monotonic() > deadline:
+                    late = [r for r in range(self.world) if int(self._gens[r]) < gen]
+                    raise TimeoutError(f"rank {self.rank}: ranks {late} did not reach barrier {gen}")
+
+    def barrier(self):
+        self._gen += 1
+        self._gens[self.rank] = self._gen
+        self._wait_all(self._gen)
+
+    def allgather_bytes(self, blob: bytes):
+        if len(blob) > _BLOB_MAX:
+            raise ValueError(f"blob of {len(blob)} bytes exceeds {_BLOB_MAX}")
+        off = self._slot(self.rank)
+        self._mm[off + 8: off + 16] = struct.pack("<q", len(blob))
+        self._mm[off + 16: off + 16 + len(blob)] = blob
+        self.barrier()                                   # everyone has written
+        out = []
+        for r in range(self.world):
+            o = self._slot(r)
+            (n,) = struct.unpack("<q", self._mm[o + 8: o + 16])
+            out.append(bytes(self._mm[o + 16: o + 16 + n]))
+        self.barrier()                                   # everyone has read: slots may be reused
+        return out
+
+    def broadcast_bytes(self, blob: Optional[bytes], src: int = 0) -> bytes:
+        return self.allgather_bytes(blob if self.rank == src else b"")[src]
+
+    def max(self, value: float) -> float:
+        vals = self.allgather_bytes(struct.pack("<d", float(value)))
+        return max(struct.unpack("<d", v)[0] for v in vals)
+
+    def gather_floats(self, value: float):
+        return [struct.unpack("<d", v)[0] for v in self.allgather_bytes(struct.pack("<d", float(value)))]
+
+    def close(self):
+        if getattr(self, "_mm", None) is None:
+            return
+        try:
+            self.barrier()
+        except TimeoutError:
+            pass
+        self._gens = None
+        try:
+            self._mm.close()
+        except BufferError:
+            pass
+        self._mm = None
+        if self.rank == 0:
+            for p in (self.path,):
+                try:
+                    os.unlink(p)
+                except OSError:
+                    pass
+            try:
+                os.rmdir(self.directory)
+            except OSError:
+                pass
+
+
+# --------------------------------------------------------------------------------------
+# result collection
+# --------------------------------------------------------------------------------------
+class SharedResult:
+    """One host result array in POSIX shared memory that every rank writes its own block
+    into ("G parallel D2H copies straight into the host result").  With a
+    GPU the mapping is pinned (``pcx_host_register``) so the copies are asynchronous and
+    run at PCIe rate; ``pinned`` says whether that succeeded."""
+
+    def __init__(self, group: HostGroup, n_values: int, device: Optional[int] = None, name: str = "result"):
+        self.group, self.n = group, int(n_values)
+        self.path = os.path.join(group.directory, f"{name}.f64")
+        nbytes = max(8, self.n * 8)
+        if group.rank == 0:
+            with open(self.path, "wb") as f:
+                f.truncate(nbytes)
+        group.barrier()
+        fd = os.open(self.path, os.O_RDWR)
+        try:
+            self._mm = mmap.mmap(fd, nbytes)
+        finally:
+            os.close(fd)
+        self.array = np.frombuffer(self._mm, dtype=np.float64, count=self.n)
+        self.pinned = False
+        self._lib = None
+        if device is not None:
+            from . import _lib
+            self._lib = _lib.load()
+            self._addr = ctypes.addressof(ctypes.c_char.from_buffer(self._mm))
+            self.pinned = self._lib.pcx_host_register(device, ctypes.c_void_p(self._addr), nbytes) == 0
+        group.barrier()
+
+    def address(self, offset_values: int = 0) -> int:
+        return ctypes.addressof(ctypes.c_char.from_buffer(self._mm)) + 8 * int(offset_values)
+
+    def close(self):
+        if self._mm is None:
+            return
+        if self.pinned:
+            self._lib.pcx_host_unregister(ctypes.c_void_p(self._addr))
+            self.pinned = False
+        self.group.barrier()
+        self.array = None
+        try:
+            self._mm.close()
+        except BufferError:
+            pass
+        self._mm = None
+        if self.group.rank == 0:
+            try:
+                os.unlink(self.path)
+            except OSError:
+                pass
+
+
+class RcclComm:
+    """``pcx_comm`` of the C ABI: an RCCL communicator over the ranks of a :class:`HostGroup`
+    (rank 0 draws the unique id, the group hands it round)."""
+
+    def __init__(self, group: HostGroup, device: int):
+        from . import _lib
+        self._libmod = _lib
+        self.lib = _lib.load()
+        self.group, self.device = group, device
+        uid = ctypes.create_string_buffer(128)
+        if group.rank == 0:
+            _lib.check(self.lib.pcx_comm_unique_id(uid), self.lib)
+        blob = group.broadcast_bytes(uid.raw if group.rank == 0 else None, 0)
+        self.handle = ctypes.c_void_p()
+        _lib.check(self.lib.pcx_comm_create(device, group.rank, group.world, blob, ctypes.byref(self.handle)),
+                   self.lib)
+        ver = ctypes.c_int32(0)
+        _lib.check(self.lib.pcx_comm_info(self.handle, None, None, None, ctypes.byref(ver)), self.lib)
+        self.rccl_version = int(ver.value)
+
+    def stream(self) -> ctypes.c_void_p:
+        st = ctypes.c_void_p()
+        self._libmod.check(self.lib.pcx_comm_stream(self.handle, ctypes.byref(st)), self.lib)
+        return st
+
+    def gatherv_dev(self, d_send, d_recv, counts: np.ndarray, offsets: np.ndarray, root: int = 0, stream=None):
+        """Enqueue the gather (device pointers as ints / c_void_p); does not synchronize."""
+        c = np.ascontiguousarray(counts, dtype=np.int64)
+        o = np.ascontiguousarray(offsets, dtype=np.int64)
+        self._libmod.check(self.lib.pcx_comm_gatherv_dev(self.handle, d_send, d_recv, self._libmod.p_i64(c),
+                                                         self._libmod.p_i64(o), root, stream), self.lib)
+
+    def max(self, value: float) -> float:
+        v = ctypes.c_double(float(value))
+        self._libmod.check(self.lib.pcx_comm_allreduce_max(self.handle, ctypes.byref(v)), self.lib)
+        return float(v.value)
+
+    def barrier(self):
+        self._libmod.check(self.lib.pcx_comm_barrier(self.handle), self.lib)
+
+    def close(self):
+        if self.handle:
+            self.lib.pcx_comm_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+def eval_sharded(evaluate: Callable[[np.ndarray], np.ndarray], points: np.ndarray, group: HostGroup,
+                 width: int = 1, dst: int = 0):
+    """Evaluate ``points`` (same array on every rank) block-wise: each rank runs ``evaluate``
+    (a model's ``vectorized_eval_batch`` / ``eval_batch`` bound to this rank's GPU) on its own
+    row block and stores the values in its slice of a shared host array -- no collective.
+    Returns the full ``(N,)`` (or ``(N, width)``) array on rank ``dst`` and ``None`` elsewhere."""
+    n = points.shape[0]
+    lo, hi = shard_bounds(n, group.rank, group.world)
+    res = SharedResult(group, n * width)
+    try:
+        if hi > lo:
+            local = np.asarray(evaluate(points[lo:hi]), dtype=np.float64).reshape(-1)
+            if local.size != (hi - lo) * width:
+                raise ValueError(f"evaluate returned {local.size} values for {hi - lo} rows x {width}")
+            res.array[lo * width: hi * width] = local
+        group.barrier()
+        full = None
+        if group.rank == dst:
+            full = np.array(res.array, copy=True)
+            if width > 1:
+                full = full.reshape(n, width)
+    finally:
+        res.close()
+    return full

@@ -1,7 +1,12 @@
-"""World-size-2 run of the batch-sharding path on CPU (gloo): each rank evaluates its own
-row block and the blocks are gathered on rank 0.  The per-rank evaluator here is the CPU
-oracle (tests may use it); on a GPU node the evaluator is the HIP path and the backend is
-nccl (= RCCL) -- the sharding / gather code is the same."""
+"""World-size-2 runs of the batch-sharding path on CPU.  Each rank evaluates its own row
+block and the blocks meet in one host array (pychebyshev_amd.distributed: HostGroup +
+SharedResult -- the package itself never imports torch).  The per-rank evaluator here is the
+CPU oracle (tests may use it); on a GPU node it is the HIP path and the device-side gather is
+RCCL (tests/test_gpu_comm.py) -- the sharding code is the same.
+
+Two launchers are covered: plain child processes with RANK/WORLD_SIZE/PCX_RDZV_DIR (what
+bench.py --gpus N starts itself) and `python -m torch.distributed.run` (how the driver starts
+bench.py); under the latter the result is also cross-checked against a gloo gather."""
 import os
 import socket
 import subprocess
@@ -9,8 +14,10 @@ import sys
 import textwrap
 
 import numpy as np
+import pytest
 
 from conftest import ROOT
+from pychebyshev_amd.distributed import shard_bounds, shard_table
 
 
 def _free_port():
@@ -23,39 +30,108 @@ WORKER = textwrap.dedent("""
     import os, sys
     import numpy as np
     sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))
-    import torch.distributed as dist
-    import functions as F
     import oracle
-    from pychebyshev_amd.distributed import eval_sharded, shard_bounds, gather_results
-    dist.init_process_group("gloo")
-    rank, world = dist.get_rank(), dist.get_world_size()
+    from pychebyshev_amd.distributed import HostGroup, eval_sharded, shard_bounds
+    assert "torch" not in sys.modules, "the package must not import torch"
+    use_gloo = {use_gloo!r}
+    group = HostGroup.from_env(timeout=120)
+    rank, world = group.rank, group.world
+    assert world == 2
     g = np.load(os.path.join({root!r}, "tests", "golden", "g1_sincos2d.npz"))
     model = oracle.BaryModel([g["nodes0"], g["nodes1"]], [g["weights0"], g["weights1"]],
                              [g["diff0"], g["diff1"]], g["tensor"])
+    ev = lambda block: oracle.bary_eval_batch(model, block, [0, 0])
+    # host-level collectives
+    blobs = group.allgather_bytes(b"rank-%d" % rank)
+    assert blobs == [b"rank-0", b"rank-1"]
+    assert group.broadcast_bytes(b"x" * 128 if rank == 0 else None, 0) == b"x" * 128
+    assert group.max(10.0 + rank) == 11.0
+    assert group.gather_floats(float(rank)) == [0.0, 1.0]
+    for i in range(50):
+        group.barrier()
     for n in (1001, 7, 1, 0, 4096):
         pts = np.random.default_rng(3).uniform(-1, 1, (n, 2))
-        full = eval_sharded(lambda block: oracle.bary_eval_batch(model, block, [0, 0]) if len(block) else np.empty(0),
-                            pts)
+        full = eval_sharded(ev, pts, group)
         if rank == 0:
-            want = oracle.bary_eval_batch(model, pts, [0, 0]) if n else np.empty(0)
+            want = ev(pts) if n else np.empty(0)
             assert full.shape == (n,) and np.array_equal(full, want), n
         else:
             assert full is None
+    # (N, m) results (multi-spec evaluation): width = 2, gathered on rank 1
+    pts = np.random.default_rng(4).uniform(-1, 1, (333, 2))
+    two = lambda block: np.column_stack([oracle.bary_eval_batch(model, block, [0, 0]),
+                                         oracle.bary_eval_batch(model, block, [1, 0])])
+    full = eval_sharded(two, pts, group, width=2, dst=1)
+    if rank == 1:
+        assert np.array_equal(full, two(pts))
+    else:
+        assert full is None
     lo, hi = shard_bounds(1001, rank, world)
     assert (lo, hi) == ((0, 501) if rank == 0 else (501, 1001))
-    dist.barrier()
-    dist.destroy_process_group()
+    if use_gloo:
+        # the same blocks through torch.distributed (gloo): the launcher's own collective
+        import torch, torch.distributed as dist
+        dist.init_process_group("gloo")
+        assert dist.get_rank() == rank and dist.get_world_size() == world
+        pts = np.random.default_rng(5).uniform(-1, 1, (1001, 2))
+        lo, hi = shard_bounds(1001, rank, world)
+        per = 501
+        buf = torch.zeros(per, dtype=torch.float64)
+        buf[: hi - lo] = torch.from_numpy(ev(pts[lo:hi]))
+        outs = [torch.empty_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, outs, dst=0)
+        mine = eval_sharded(ev, pts, group)
+        if rank == 0:
+            assert np.array_equal(torch.cat(outs)[:1001].numpy(), mine)
+        dist.barrier()
+        dist.destroy_process_group()
+    group.close()
     sys.stdout.write("rank-%d-ok\\n" % rank)
     sys.stdout.flush()
 """)
 
 
-def test_sharded_eval_and_gather_world_size_2(tmp_path):
+def test_shard_tables():
+    assert shard_bounds(10, 0, 4) == (0, 3) and shard_bounds(10, 3, 4) == (9, 10)
+    assert shard_bounds(2, 3, 4) == (2, 2)                       # more ranks than rows: empty tail blocks
+    c, o = shard_table(10, 4)
+    assert c.tolist() == [3, 3, 3, 1] and o.tolist() == [0, 3, 6, 9]
+    c, o = shard_table(5, 2, width=6)
+    assert c.tolist() == [18, 12] and o.tolist() == [0, 18]
+    c, o = shard_table(0, 3)
+    assert c.tolist() == [0, 0, 0] and o.tolist() == [0, 0, 0]
+    with pytest.raises(ValueError):
+        shard_bounds(10, 4, 4)
+
+
+def test_sharded_eval_plain_child_processes(tmp_path):
+    """The launcher bench.py uses for --gpus N: N children with RANK / WORLD_SIZE / PCX_RDZV_DIR."""
     script = tmp_path / "worker.py"
-    script.write_text(WORKER.format(root=ROOT))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), OMP_NUM_THREADS="2")
+    script.write_text(WORKER.format(root=ROOT, use_gloo=False))
+    rdzv = tmp_path / "rdzv"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", PCX_RDZV_DIR=str(rdzv),
+                   OMP_NUM_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=300) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: {so[-1000:]}{se[-3000:]}"
+        assert f"rank-{r}-ok" in so
+    assert not rdzv.exists() or not any(rdzv.iterdir())          # rank 0 cleaned the rendezvous up
+
+
+def test_sharded_eval_under_torchrun_gloo(tmp_path):
+    """Launched the way the driver launches bench.py; HostGroup finds its peers from the
+    launcher's environment, and the result equals a gloo gather of the same blocks."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER.format(root=ROOT, use_gloo=True))
+    port = str(_free_port())
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=port, OMP_NUM_THREADS="2")
+    env.pop("PCX_RDZV_DIR", None)
     res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-                          "--master-addr", "127.0.0.1", "--master-port", env["MASTER_PORT"], str(script)],
+                          "--master-addr", "127.0.0.1", "--master-port", port, str(script)],
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "rank-0-ok" in res.stdout and "rank-1-ok" in res.stdout

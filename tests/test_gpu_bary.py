@@ -544,45 +544,3 @@ def test_fuzz_random_tensor_shapes_against_oracle(oracle_mod):
         got = c.vectorized_eval_batch(pts, spec)
         scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(T))))
         assert np.max(np.abs(got - ref)) <= 1e-11 * scale, (case, shape, spec, npts)
-
-
-# ------------------------------------------------------------------ sharded evaluation over RCCL (one rank here)
-_NCCL_WORKER = r"""
-import os, sys
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-import numpy as np
-import torch
-import torch.distributed as dist
-sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests", "golden"))
-import functions as F
-from pychebyshev_amd import ChebyshevApproximation
-from pychebyshev_amd.distributed import eval_sharded
-g = np.load(os.path.join(sys.argv[1], "tests", "golden", "g2_bs5d.npz"))
-c = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES)
-pts = g["points"][:1000]
-torch.cuda.set_device(0)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + sys.argv[2], rank=0, world_size=1,
-                        device_id=torch.device("cuda", 0))
-try:
-    got = eval_sharded(lambda p: c.vectorized_eval_batch(p, [0] * 5), pts)
-finally:
-    dist.destroy_process_group()
-assert np.array_equal(got, c.vectorized_eval_batch(pts, [0] * 5))
-print("SHARDED-OK")
-"""
-
-
-def test_eval_sharded_over_nccl_with_one_rank():
-    """The multi-GPU entry point on its real backend (nccl = RCCL), rehearsed with the single
-    rank a one-GPU box allows; world size 2 is covered on CPU with gloo (test_distributed_cpu.py).
-    Runs in a process of its own, as a rank does (torch brings its own HIP runtime)."""
-    import socket
-    import subprocess
-    import sys
-    from conftest import ROOT
-    with socket.socket() as sock:                 # a free rendezvous port
-        sock.bind(("127.0.0.1", 0))
-        port = str(sock.getsockname()[1])
-    res = subprocess.run([sys.executable, "-c", _NCCL_WORKER, ROOT, port], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
-                         text=True, timeout=600)
-    assert res.returncode == 0 and "SHARDED-OK" in res.stdout, res.stderr[-2000:]
