@@ -221,7 +221,7 @@ class TTWork(Workload):
                 str(list(built.tt_ranks)).replace(" ", ""), f"{n_points:,}")
             self.flop_per_eval = 2.0 * sum((11 + 1) * a * b for a, b in zip(built.tt_ranks[:-1], built.tt_ranks[1:]))
             self.bytes_per_eval = 48.0
-            self.kernel = "k_tt_eval_wfirst<8,3,1>"
+            self.kernel = "k_tt_eval_d4<2>"
         else:
             rng = np.random.default_rng(16)
             ranks = [1] + [16] * 9 + [1]

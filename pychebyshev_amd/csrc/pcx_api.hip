@@ -1102,7 +1102,13 @@ struct pcx_tt {
     TTWPlan wplan;
     long w_resident = 0;  // workgroups of the W-first kernel the device keeps resident (lazy)
     double *d_img = nullptr;
-    int variant = 0;      // 0 auto, 1 direct form, 2 W-first form
+    // small-rank direct form on the 4x4x4 MFMA (ranks <= 12, n <= 16, packed cores resident in LDS)
+    int d4RA = 0;         // 0 = not available, else left/right chunks of 4: 1, 2, 3
+    bool d4_preferred = true;   // auto: the cheaper of this form and the W-first form (cycle estimate at create)
+    TTD4Plan d4plan;
+    long d4_resident = 0;
+    double *d_img4 = nullptr;
+    int variant = 0;      // 0 auto, 1 direct form (16x16x4), 2 W-first form, 3 direct form (4x4x4)
     bool generic = false; // ranks > 64: wave-per-point kernel on the plain cores
     TTGeneric gi;
     double *d_cores = nullptr;
@@ -1118,6 +1124,7 @@ extern "C" int pcx_tt_destroy(pcx_tt *h) {
     (void)hipFree(h->d_frag);
     (void)hipFree(h->d_last);
     (void)hipFree(h->d_img);
+    (void)hipFree(h->d_img4);
     (void)hipFree(h->d_cores);
     h->s_pts.release(); h->s_out.release();
     h->pin.release();
@@ -1258,6 +1265,68 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
             else hipLaunchKernelGGL(k_tt_pack_wfirst<12>, grid, block, 0, h->stream, src, dst, ranks[k], n_nodes[k], ranks[k + 1], ks, h->wplan.ntiles[k], last);
         }
     }
+    // 4x4x4 direct-form image (tt_kernels.h, k_tt_eval_d4): packed on the host from the caller's
+    // cores -- dim 0: [s][slot][NMP], mid dims: [j][c][slot][NMP], last dim: [4 RA][n].
+    if (h->rmax <= 12 && nmax <= PCX_D4_MAX_NODES) {
+        const int RA = (h->rmax + 3) / 4;
+        const int NMP = RA == 3 ? 4 : RA;
+        long total = 0;
+        for (int k = 0; k < d; ++k) {
+            h->d4plan.lds_off[k] = (int)total;
+            const long nk = n_nodes[k];
+            total += (k == d - 1) ? 4L * RA * nk : (k == 0) ? ((nk + 3) / 4) * 16L * NMP : nk * RA * 16L * NMP;
+        }
+        for (int k = d; k < PCX_MAX_DIMS; ++k) h->d4plan.lds_off[k] = 0;
+        h->d4plan.total = (int)total;
+        const size_t per_wave = (size_t)16 * d + 16 * 6;
+        const size_t lds_bytes = ((size_t)total + 2 * 16 * d + 4 * per_wave) * sizeof(double);
+        if (lds_bytes <= 72 * 1024) {     // two workgroups per CU at least
+            std::vector<double> img((size_t)total, 0.0);
+            auto G = [&](int k, int a, int j, int b) -> double {
+                if (a >= ranks[k] || b >= ranks[k + 1] || j >= n_nodes[k]) return 0.0;
+                return cores_cat[coff[k] + ((long)a * n_nodes[k] + j) * ranks[k + 1] + b];
+            };
+            for (int k = 0; k < d - 1; ++k) {
+                double *dst = img.data() + h->d4plan.lds_off[k];
+                if (k == 0) {
+                    const int ks0 = (n_nodes[0] + 3) / 4;
+                    for (int s0 = 0; s0 < ks0; ++s0)
+                        for (int k4 = 0; k4 < 4; ++k4)
+                            for (int i = 0; i < 4; ++i)
+                                for (int m = 0; m < RA; ++m)
+                                    dst[s0 * 16 * NMP + (k4 * 4 + i) * NMP + m] = G(0, 0, 4 * s0 + k4, 4 * m + i);
+                } else {
+                    for (int j = 0; j < n_nodes[k]; ++j)
+                        for (int c = 0; c < RA; ++c)
+                            for (int k4 = 0; k4 < 4; ++k4)
+                                for (int i = 0; i < 4; ++i)
+                                    for (int m = 0; m < RA; ++m)
+                                        dst[(j * RA + c) * 16 * NMP + (k4 * 4 + i) * NMP + m] = G(k, 4 * c + k4, j, 4 * m + i);
+                }
+            }
+            {
+                double *dst = img.data() + h->d4plan.lds_off[d - 1];
+                const int nl = n_nodes[d - 1];
+                for (int a = 0; a < 4 * RA; ++a)
+                    for (int j = 0; j < nl; ++j) dst[a * nl + j] = G(d - 1, a, j, 0);
+            }
+            if (hipMalloc((void **)&h->d_img4, img.size() * sizeof(double)) == hipSuccess &&
+                hipMemcpy(h->d_img4, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess)
+                h->d4RA = RA;
+            // which small-rank form auto takes: FP64-pipe cycles per 16 points and middle dimension,
+            // from tools/tt_rate_probe.py (profiles/r02_tt_rate_probe.txt): the 4x4x4 form issues
+            // n RA^2 instructions of ~20 cycles and pads nothing; the W-first form R^2/16 ceil(n/4)
+            // instructions of ~75 cycles plus a fold.  Ranks <= 4 always favour the 4x4x4 form.
+            if (h->wR && RA > 1) {
+                long c4 = 0, cw = 0;
+                for (int k = 1; k < d - 1; ++k) {
+                    c4 += (long)n_nodes[k] * RA * RA * 20 + 100;
+                    cw += (long)(h->wR * h->wR / 16) * h->wplan.ks * 75 + 160;
+                }
+                h->d4_preferred = c4 <= cw;
+            }
+        }
+    }
     hipError_t e1 = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(h->stream);
     (void)hipFree(d_cores);
@@ -1292,6 +1361,28 @@ static int tt_launch_wfirst(pcx_tt *h, const double *d_pts, long N, double *d_ou
     return PCX_OK;
 }
 
+template <int RA>
+static int tt_launch_d4(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
+    auto kern = k_tt_eval_d4<RA>;
+    const size_t per_wave = (size_t)16 * h->dims.d + 16 * 6;
+    size_t lds = ((size_t)h->d4plan.total + (size_t)2 * 16 * h->dims.d + 4 * per_wave) * sizeof(double);
+    if (h->d4_resident == 0) {
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int per_cu = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, lds));
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, h->device));
+        h->d4_resident = std::max(1, per_cu) * std::max(1, prop.multiProcessorCount);
+    }
+    long batches = (N + 63) / 64;
+    // persistent workgroups, four per resident slot: later rounds of workgroups even out the tail
+    long blocks = std::min<long>(batches, h->d4_resident * 4);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->d4plan, h->d_img4, d_pts, d_out, N);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
 template <int R, int NT>
 static int tt_launch_wfirst_ks(pcx_tt *h, const double *d_pts, long N, double *d_out, hipStream_t st) {
     switch (h->wplan.ks) {
@@ -1319,6 +1410,12 @@ static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipS
         return PCX_OK;
     }
     if (h->variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
+    if (h->variant == 3 && !h->d4RA) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 direct TT kernel does not cover this model");
+    if (h->d4RA && (h->variant == 3 || (h->variant == 0 && (!h->wR || h->d4_preferred)))) {
+        if (h->d4RA == 1) return tt_launch_d4<1>(h, d_pts, N, d_out, st);
+        if (h->d4RA == 2) return tt_launch_d4<2>(h, d_pts, N, d_out, st);
+        return tt_launch_d4<3>(h, d_pts, N, d_out, st);
+    }
     if (h->wR && h->variant != 1) {
         if (h->wR == 4) return tt_launch_wfirst_ks<4, 4>(h, d_pts, N, d_out, st);
         if (h->wR == 8) return tt_launch_wfirst_ks<8, 1>(h, d_pts, N, d_out, st);
@@ -1386,8 +1483,9 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
 
 extern "C" int pcx_tt_set_kernel(pcx_tt *h, int variant) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
-    if (variant < 0 || variant > 2) return fail(PCX_ERR_INVALID, "variant %d outside [0, 2]", variant);
+    if (variant < 0 || variant > 3) return fail(PCX_ERR_INVALID, "variant %d outside [0, 3]", variant);
     if (variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
+    if (variant == 3 && !h->d4RA) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 direct TT kernel does not cover this model");
     if (variant != 0 && h->generic) return fail(PCX_ERR_UNSUPPORTED, "ranks above 64 run on the generic kernel only");
     h->variant = variant;
     return PCX_OK;

@@ -541,3 +541,224 @@ k_tt_eval_wfirst(TTDims dims, TTWPlan plan, const double *__restrict__ img,
     }
   }   // batch loop
 }
+
+// =====================================================================================
+// Small-rank direct form on v_mfma_f64_4x4x4_4b_f64 (ranks <= 12, n <= 16): the default for
+// small models since round 2.
+//     v'[b, p] = sum_{(j, c)} sum_k G[a = 4c + k, j, b] * z_j[c][k, p],   z_j[c] = v[4c + k, p] T_j(x_p)
+//   four blocks = the four 4-point groups of a wave's 16 points
+//   A lane = 16 k + 4 blk + i : G[a = 4c + k][j][b = 4m + i], identical in the four blocks -> a
+//                               broadcast LDS read brings the RA output chunks m of one (j, c)
+//   B lane = 16 k + 4 blk + jj: z_j[c] of point 4 blk + jj, left-rank row k
+//   D lane = 16 i + 4 blk + jj: v'[4m + i] of that point -- exactly the row (k := i) the lane
+//                               needs as B operand of left chunk c = m in the next dimension:
+//                               the chain runs with NO cross-lane movement and no fold.
+// The B operands come from the Chebyshev recurrence applied to the PRODUCTS,
+//     z_{j+1} = 2 x z_j - z_{j-1},  z_0 = v,  z_{-1} = x v     (T_{-1} = T_1),
+// one FMA per (j, c): no table of T_j and no per-MFMA multiply.  Against the W-first form:
+// no padding of 8 rows to 16, none of n to a multiple of 4 (138 instead of 150 16-cycle
+// instructions for ranks [1,8,8,8,6,1], n = 11), 180 instead of 230 other vector instructions
+// per 16 points, and 80 VGPRs (6 waves per SIMD).  What bounds it (profiles/r02_tt5d_*): FP64
+// MFMA and FP64/other VALU do not overlap on gfx950 -- measured cycles per 16-point batch per
+// SIMD = SQ_VALU_MFMA_BUSY_CYCLES + SQ_ACTIVE_INST_VALU for every form tried
+// (tools/tt_wfirst_lab.hip).
+// Dimension 0 (left rank 1) is a GEMM over the nodes alone (B = T_{4s+k}(x), stride-4
+// recurrence seeded through a 6-double LDS record per point, so that each lane group picks
+// T_k and T_{4-k} by ADDRESS, not by selects); the last dimension (right rank 1) is a VALU dot
+// product split over the four lane groups.  Node counts are dispatched to fully unrolled
+// bodies so that the LDS reads run ahead of the MFMAs.
+// image: dim 0: [s][16 slots][NMP]; mid dims: [j][c < RA][16 slots][NMP] with slot = 4 k + i and
+//        the RA values m of a slot contiguous (NMP = 1, 2, 4 doubles: one aligned read);
+//        last dim: [4 RA rows a][n] zero padded.
+// =====================================================================================
+typedef double pcx_d2 __attribute__((ext_vector_type(2)));
+
+template <int RA> struct D4Frag;
+template <> struct D4Frag<1> {
+    double v[1];
+    static constexpr int NMP = 1;
+    __device__ __forceinline__ void load(const double *p) { v[0] = p[0]; }
+};
+template <> struct D4Frag<2> {
+    double v[2];
+    static constexpr int NMP = 2;
+    __device__ __forceinline__ void load(const double *p) { const pcx_d2 t = *(const pcx_d2 *)p; v[0] = t.x; v[1] = t.y; }
+};
+template <> struct D4Frag<3> {
+    double v[3];
+    static constexpr int NMP = 4;
+    __device__ __forceinline__ void load(const double *p) { const pcx_d2 t = *(const pcx_d2 *)p; v[0] = t.x; v[1] = t.y; v[2] = p[2]; }
+};
+
+struct TTD4Plan {
+    int lds_off[PCX_MAX_DIMS];  // offset (doubles) of dim k's block inside the LDS image
+    int total;                  // doubles in the LDS image
+};
+
+#define PCX_D4_MAX_NODES 16
+
+template <int RA, int NJ>
+__device__ __forceinline__ void tt_d4_mid(const double *fk, double x, double (&v)[RA]) {
+    constexpr int NMP = D4Frag<RA>::NMP;
+    const double x2 = x + x;
+    double zc[RA], zp[RA], acc[RA];
+#pragma unroll
+    for (int c = 0; c < RA; ++c) { zc[c] = v[c]; zp[c] = v[c] * x; }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int c = 0; c < RA; ++c) {
+            D4Frag<RA> a;
+            a.load(fk + (j * RA + c) * 16 * NMP);
+#pragma unroll
+            for (int m = 0; m < RA; ++m)
+                acc[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[m], zc[c], (j == 0 && c == 0) ? 0.0 : acc[m], 0, 0, 0);
+        }
+        if (j + 1 < NJ) {
+#pragma unroll
+            for (int c = 0; c < RA; ++c) { const double zn = __builtin_fma(x2, zc[c], -zp[c]); zp[c] = zc[c]; zc[c] = zn; }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < RA; ++m) v[m] = acc[m];
+}
+
+// y_partial = sum_c v[c] * sum_j T_j(x) G[a = 4c + g][j]; gl -> row g of the [4 RA][NJ] table
+template <int RA, int NJ>
+__device__ __forceinline__ double tt_d4_last(const double *gl, double x, const double (&v)[RA]) {
+    const double x2 = x + x;
+    double w[RA], tp = 1.0, tc = x;
+#pragma unroll
+    for (int c = 0; c < RA; ++c) w[c] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+#pragma unroll
+        for (int c = 0; c < RA; ++c) w[c] = __builtin_fma(tp, gl[c * 4 * NJ + j], w[c]);
+        if (j + 1 < NJ) { const double tn = __builtin_fma(x2, tc, -tp); tp = tc; tc = tn; }
+    }
+    double y = v[0] * w[0];
+#pragma unroll
+    for (int c = 1; c < RA; ++c) y = __builtin_fma(v[c], w[c], y);
+    return y;
+}
+
+#define PCX_D4_NODE_SWITCH(n, CALL)                                                                     \
+    switch (n) {                                                                                        \
+    case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; case 4: CALL(4); break;     \
+    case 5: CALL(5); break; case 6: CALL(6); break; case 7: CALL(7); break; case 8: CALL(8); break;     \
+    case 9: CALL(9); break; case 10: CALL(10); break; case 11: CALL(11); break; case 12: CALL(12); break; \
+    case 13: CALL(13); break; case 14: CALL(14); break; case 15: CALL(15); break; default: CALL(16); break; }
+
+// Persistent workgroups of 4 waves; a wave owns 16 points per batch.  The query rows of the
+// NEXT batch are fetched (coalesced) while the current one is computed and mapped to [-1, 1]
+// on their way into the wave's LDS slice: s = (x - a) * (2 / (b - a)) - 1 in one subtraction and
+// one FMA (the reference divides, 2 (x - a) / (b - a) - 1: the two differ by at most 2 ulp of s,
+// far inside the TT tolerance; the division sequence cost 70 FP64 instructions per batch).
+template <int RA>
+__global__ void __launch_bounds__(256, 4)
+k_tt_eval_d4(TTDims dims, TTD4Plan plan, const double *__restrict__ img, const double *__restrict__ pts,
+             double *__restrict__ out, long N) {
+    constexpr int NMP = D4Frag<RA>::NMP;
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c16 = lane & 15;
+    const int d = dims.d;
+    const int cnt = 16 * d;                         // doubles in a wave's block of query rows
+    for (int i = threadIdx.x; i < plan.total; i += 256) lds[i] = img[i];
+    // element i of a wave's block is column i % d: table of its storage dimension's bounds
+    double *lo_t = lds + plan.total, *wd_t = lo_t + cnt;
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+        const int c = i % d;
+        double lo = 0.0, wd = 1.0;
+        for (int kk = 0; kk < d; ++kk)
+            if (dims.col[kk] == c) { lo = dims.lo[kk]; wd = dims.hi[kk] - dims.lo[kk]; }
+        lo_t[i] = lo;
+        wd_t[i] = 2.0 / wd;
+    }
+    double *xs = wd_t + cnt + (size_t)wave * (cnt + 16 * 6);
+    double *seed = xs + cnt + c16 * 6;              // this lane's point: {T_0 .. T_4, 2 T_4}(x_0)
+    const int a_idx = ((lane >> 4) * 4 + (lane & 3)) * NMP;
+    const long nbatch = (N + 63) / 64;
+    constexpr int PFMAX = 4;                        // 16 d / 64 staged elements per lane, d <= 16
+    const int npf = (cnt + 63) >> 6;
+    double pf[PFMAX];
+    auto fetch = [&](long batch) {
+        const long base = (batch * 4 + wave) * 16;
+        const long first = base * d, avail = (N - base) * (long)d;
+#pragma unroll
+        for (int r = 0; r < PFMAX; ++r)
+            if (r < npf) {
+                const int i = lane + 64 * r;
+                pf[r] = (i < cnt && i < avail) ? pts[first + i] : 0.0;
+            }
+    };
+    if ((long)blockIdx.x < nbatch) fetch(blockIdx.x);
+    __syncthreads();
+    const int ks0 = (dims.n[0] + 3) >> 2;
+
+    for (long batch = blockIdx.x; batch < nbatch; batch += gridDim.x) {
+        const long base = (batch * 4 + wave) * 16;
+        // wave-private LDS slice: LDS operations of one wave execute in order, no barrier needed
+#pragma unroll
+        for (int r = 0; r < PFMAX; ++r)
+            if (r < npf) {
+                const int i = lane + 64 * r;
+                if (i < cnt) xs[i] = __builtin_fma(pf[r] - lo_t[i], wd_t[i], -1.0);
+            }
+        if (batch + gridDim.x < nbatch) fetch(batch + gridDim.x);
+        double v[RA];
+        if (d > 1) {
+            const double x = xs[c16 * d + dims.col[0]];
+            const double x2 = x + x, t2 = __builtin_fma(x2, x, -1.0), t3 = __builtin_fma(x2, t2, -x),
+                         t4 = __builtin_fma(x2, t3, -t2);
+            // the compiler must not move the reads below above these writes (the hardware keeps
+            // a wave's LDS operations in order)
+            asm volatile("" ::: "memory");
+            if (g == 0) {
+                *(pcx_d2 *)(seed) = (pcx_d2){1.0, x};
+                *(pcx_d2 *)(seed + 2) = (pcx_d2){t2, t3};
+                *(pcx_d2 *)(seed + 4) = (pcx_d2){t4, t4 + t4};
+            }
+            asm volatile("" ::: "memory");
+            double up = seed[4 - g], uc = seed[g];  // T_{4-g} = T_{|g-4|}, T_g
+            const double c4 = seed[5];
+            const double *f0 = lds + plan.lds_off[0] + a_idx;
+            double acc[RA];
+#pragma unroll
+            for (int m = 0; m < RA; ++m) acc[m] = 0.0;
+            for (int s = 0; s < ks0; ++s) {
+                D4Frag<RA> a;
+                a.load(f0 + s * 16 * NMP);
+#pragma unroll
+                for (int m = 0; m < RA; ++m) acc[m] = __builtin_amdgcn_mfma_f64_4x4x4f64(a.v[m], uc, acc[m], 0, 0, 0);
+                const double un = __builtin_fma(c4, uc, -up);   // T_{4(s+1)+g} = 2 T_4 T_{4s+g} - T_{|4(s-1)+g|}
+                up = uc;
+                uc = un;
+            }
+#pragma unroll
+            for (int m = 0; m < RA; ++m) v[m] = acc[m];
+        } else {
+#pragma unroll
+            for (int m = 0; m < RA; ++m) v[m] = (m == 0 && g == 0) ? 1.0 : 0.0;
+        }
+        for (int k = 1; k < d - 1; ++k) {
+            const double x = xs[c16 * d + dims.col[k]];
+            const double *fk = lds + plan.lds_off[k] + a_idx;
+#define PCX_D4_MID(NJ) tt_d4_mid<RA, NJ>(fk, x, v)
+            PCX_D4_NODE_SWITCH(dims.n[k], PCX_D4_MID)
+#undef PCX_D4_MID
+        }
+        {
+            const int nl = dims.n[d - 1];
+            const double *gl = lds + plan.lds_off[d - 1] + g * nl;
+            const double x = xs[c16 * d + dims.col[d - 1]];
+            double y;
+#define PCX_D4_LAST(NJ) y = tt_d4_last<RA, NJ>(gl, x, v)
+            PCX_D4_NODE_SWITCH(nl, PCX_D4_LAST)
+#undef PCX_D4_LAST
+            y += __shfl_xor(y, 16, 64);
+            y += __shfl_xor(y, 32, 64);
+            const long p = base + c16;
+            if (g == 0 && p < N) out[p] = y;
+        }
+    }
+}

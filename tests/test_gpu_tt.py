@@ -71,25 +71,53 @@ def _set_tt_kernel(tt, variant):
     _lib.check(t.lib.pcx_tt_set_kernel(t.handle, variant), t.lib)
 
 
-def test_both_tt_kernel_forms_agree_with_reference():
-    """Ranks <= 12 have two kernels: the direct (node, rank)-GEMM form and the small-rank
-    "W first" form (auto picks the latter).  Both must match the reference."""
+def test_all_tt_kernel_forms_agree_with_reference():
+    """Ranks <= 12 have three kernels: the direct (node, rank)-GEMM form on the 16x16x4 MFMA (1),
+    the small-rank "W first" form (2) and the small-rank direct form on the 4x4x4 MFMA (3, what
+    auto picks for n <= 16).  All must match the reference."""
     g = golden("g4_tt_bs5d")
     for mr in (8, 15):
         tt = ChebyshevTT.from_coeff_cores(_cores(g, f"r{mr}_", 5), F.BS5_DOMAIN)
-        for variant in (1, 2, 0):
+        for variant in (1, 2, 3, 0):
             _set_tt_kernel(tt, variant)
             assert_parity(tt.eval_batch(g["points"]), g[f"r{mr}_eval"], 1e-12, f"TT r{mr} variant {variant}")
     g = golden("g5b_tt_mixed")
     dom = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
     tt = ChebyshevTT.from_coeff_cores(_cores(g, "", 4), dom)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         _set_tt_kernel(tt, variant)
         assert_parity(tt.eval_batch(g["points"]), g["out"], 1e-12, f"mixed variant {variant}")
     g = golden("g5_tt_rank16")
     tt16 = ChebyshevTT.from_coeff_cores(_cores(g, "", 10), [[-1.0, 1.0]] * 10)
     t = tt16._dev()
     assert t.lib.pcx_tt_set_kernel(t.handle, 2) == _lib.PCX_ERR_UNSUPPORTED     # rank 16 > 12
+    assert t.lib.pcx_tt_set_kernel(t.handle, 3) == _lib.PCX_ERR_UNSUPPORTED
+    assert t.lib.pcx_tt_set_kernel(t.handle, 4) == _lib.PCX_ERR_INVALID
+
+
+def test_small_rank_forms_over_rank_classes_node_counts_and_batch_tails(oracle_mod):
+    """The 4x4x4 direct form dispatches on the node count of every dimension (1..16) and pads
+    ranks to 4 / 8 / 12: seeded models over those classes, d = 1..7, ragged batch sizes around
+    the 16-point tile and the 64-point workgroup, a permuted dim_order, against the oracle."""
+    rng = np.random.default_rng(20261004)
+    cases = [(1, [7], [1, 1]), (2, [16, 1], [1, 3, 1]), (3, [2, 3, 4], [1, 2, 4, 1]),
+             (4, [5, 16, 9, 13], [1, 4, 7, 8, 1]), (5, [11] * 5, [1, 9, 12, 10, 5, 1]),
+             (7, [3, 15, 6, 1, 10, 14, 8], [1, 2, 6, 3, 8, 4, 2, 1]), (3, [12, 12, 12], [1, 12, 12, 1])]
+    for d, n, ranks in cases:
+        cores = [rng.standard_normal((ranks[k], n[k], ranks[k + 1])) / np.sqrt(ranks[k] * n[k]) for k in range(d)]
+        dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-5, 5, d), rng.uniform(0.5, 4, d))]   # storage frame
+        order = [int(v) for v in rng.permutation(d)]
+        tt = ChebyshevTT.from_coeff_cores(cores, dom, dim_order=order)
+        for npts in (1, 15, 16, 17, 63, 64, 65, 1000):
+            pts = np.empty((npts, d))
+            for k in range(d):                               # user column order[k] feeds storage dimension k
+                pts[:, order[k]] = rng.uniform(dom[k][0], dom[k][1], npts)
+            ref = oracle_mod.tt_eval_batch(cores, dom, pts, dim_order=order)
+            scale = max(float(np.max(np.abs(ref))), 1e-300)
+            for variant in (3, 2):
+                _set_tt_kernel(tt, variant)
+                got = tt.eval_batch(pts)
+                assert np.max(np.abs(got - ref)) <= 1e-12 * scale, (d, n, ranks, npts, variant)
 
 
 def test_to_dense_reproduces_the_grid_values():
@@ -303,7 +331,7 @@ def test_points_outside_the_domain_extrapolate_like_the_reference_algorithm(orac
     rng = np.random.default_rng(3)
     pts = lo + (hi - lo) * rng.uniform(-0.1, 1.1, (500, 5))
     ref = oracle_mod.tt_eval_batch(cores, F.BS5_DOMAIN, pts)
-    for variant in (1, 2):
+    for variant in (1, 2, 3):
         _set_tt_kernel(tt, variant)
         y = tt.eval_batch(pts)
         assert np.max(np.abs(y - ref)) <= 1e-11 * np.max(np.abs(ref)), variant

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device-resident eval_batch throughput of synthetic TT models over rank classes / shapes
-(the W-first kernel covers ranks <= 12, the direct MFMA kernel ranks 13..64).
+(ranks <= 12: the 4x4x4 direct kernel (n <= 16) or the W-first kernel; ranks 13..64: the 16x16x4 direct kernel).
 
     python tools/tt_rate_probe.py [--points 4000000]
 """
@@ -27,7 +27,7 @@ def rate(d, r, n, npts, variant=0):
     lib = t.lib
     if variant:
         if lib.pcx_tt_set_kernel(t.handle, variant) != 0:
-            return float("nan")
+            return float("nan"), float("nan")
     pts = rng.uniform(-1, 1, (npts, d))
     dev = _lib.default_device()
     d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
@@ -55,12 +55,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=4_000_000)
     a = ap.parse_args()
-    print(f"{'d':>3} {'rank':>4} {'n':>3}  {'auto pts/s':>12} {'frac':>6}   {'direct pts/s':>12} {'frac':>6}")
-    for d, r, n in [(5, 2, 11), (5, 4, 11), (10, 4, 11), (5, 8, 11), (5, 8, 20), (5, 12, 11), (10, 12, 11),
+    print(f"{'d':>3} {'rank':>4} {'n':>3}  {'auto pts/s':>12} {'frac':>6}   {'d4x4 pts/s':>12} {'frac':>6}   {'W-first pts/s':>13} {'frac':>6}"
+          f"   {'direct16 pts/s':>14} {'frac':>6}")
+    for d, r, n in [(5, 2, 11), (5, 4, 11), (10, 4, 11), (5, 8, 11), (5, 8, 16), (5, 8, 20), (5, 12, 11), (10, 12, 11),
                     (5, 16, 11), (10, 16, 11), (5, 32, 11), (5, 64, 11)]:
-        auto = rate(d, r, n, a.points)
-        direct = rate(d, r, n, a.points, variant=1)
-        print(f"{d:>3} {r:>4} {n:>3}  {auto[0]:12.4e} {auto[1]:6.3f}   {direct[0]:12.4e} {direct[1]:6.3f}")
+        res = [rate(d, r, n, a.points, variant=v) for v in (0, 3, 2, 1)]
+        print(f"{d:>3} {r:>4} {n:>3}  " + "   ".join(f"{x[0]:13.4e} {x[1]:6.3f}" for x in res))
 
 
 if __name__ == "__main__":
