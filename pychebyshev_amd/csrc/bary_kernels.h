@@ -128,7 +128,7 @@ __device__ __forceinline__ double code_weight(unsigned code, const double *bw_co
 //   bit-identical for every batch size.
 // grid.z = number of derivative specs evaluated in this launch (frag_tab[z]).
 //
-// 256 threads = 4 waves; dynamic LDS = 4 * (sum_n + 1) * PW * 8 bytes.
+// 256 threads = 4 waves; dynamic LDS = 4 * (sum_n + 2) * PW * 8 bytes.
 // ---------------------------------------------------------------------------------
 #define PCX_CHUNK_TILES 4
 
@@ -153,7 +153,8 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int c = lane & 15;
-    double *bw = lds + (size_t)wave * (dims.sum_n + 1) * PW;
+    double *bw = lds + (size_t)wave * plan.rows * PW;
+    const double *bwt = bw + (size_t)plan.tail_base * PW;      // tail part: what the k codes index
     const long base = ((long)blockIdx.x * 4 + wave) * PW;
     // a pointer loaded from memory is "generic" to the compiler (flat_load + combined
     // vmcnt/lgkmcnt waits); it is known to be global memory, say so
@@ -173,10 +174,13 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         for (int k = ph; k < dims.d; k += PH) {
             const double *nd = nodes + dims.off[k];
             double x = valid ? pts[row * dims.d + k] : nd[0];
-            bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + (size_t)dims.off[k] * PW + pp,
-                            PW);
+            const int trow = dims.off[k] + (k >= plan.split ? 1 : 0);
+            bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + (size_t)trow * PW + pp, PW);
         }
-        if (ph == 0) bw[(size_t)dims.sum_n * PW + pp] = 1.0;
+        if (ph == 0) {
+            bw[(size_t)(plan.tail_base - 1) * PW + pp] = 1.0;
+            bw[(size_t)(plan.rows - 1) * PW + pp] = 1.0;
+        }
     }
     __syncthreads();
 
@@ -186,11 +190,11 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     for (int s = 0; s < KS; ++s) {
         unsigned code = kcode[4 * s + g];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bw + 16 * nt + c, PW);
+        for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bwt + 16 * nt + c, PW);
         if (WIDE) {
             unsigned hi = kcode_hi[4 * s + g];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) B[nt][s] *= code_weight(hi, bw + 16 * nt + c, PW);
+            for (int nt = 0; nt < NT; ++nt) B[nt][s] *= code_weight(hi, bwt + 16 * nt + c, PW);
         }
     }
 
@@ -356,7 +360,7 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
 //   of frag[t], double-buffered, one barrier per tile) and read with a broadcast
 //   ds_read_b64 (16 distinct addresses per wave-instruction, conflict-free).
 // 512 threads = 8 waves share each staged tile; every wave owns 32 points (NT = 2).
-// dynamic LDS = 8 * (sum_n + 1) * 32 * 8 + 2 * KS * 64 * 8 bytes.
+// dynamic LDS = 8 * (sum_n + 2) * 32 * 8 + 2 * KS * 64 * 8 bytes.
 // ---------------------------------------------------------------------------------
 template <int KS>
 __global__ void __launch_bounds__(512, 2)
@@ -374,8 +378,9 @@ k_bary_mfma4(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     const int wave = threadIdx.x >> 6;
     const int g = lane >> 4;
     const int c = lane & 15;
-    double *bw = lds + (size_t)wave * (dims.sum_n + 1) * PW;
-    double *slab = lds + (size_t)8 * (dims.sum_n + 1) * PW;
+    double *bw = lds + (size_t)wave * plan.rows * PW;
+    const double *bwt = bw + (size_t)plan.tail_base * PW;
+    double *slab = lds + (size_t)8 * plan.rows * PW;
     const long base = ((long)blockIdx.x * 8 + wave) * PW;
     typedef const double __attribute__((address_space(1))) *gptr_t;
     const gptr_t frag = (gptr_t)frag_tab[blockIdx.z];
@@ -390,9 +395,13 @@ k_bary_mfma4(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         for (int k = ph; k < dims.d; k += 2) {
             const double *nd = nodes + dims.off[k];
             double x = valid ? pts[row * dims.d + k] : nd[0];
-            bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + (size_t)dims.off[k] * PW + pp, PW);
+            const int trow = dims.off[k] + (k >= plan.split ? 1 : 0);
+            bary_weights_1d(x, nd, wts + dims.off[k], dims.n[k], bw + (size_t)trow * PW + pp, PW);
         }
-        if (ph == 0) bw[(size_t)dims.sum_n * PW + pp] = 1.0;
+        if (ph == 0) {
+            bw[(size_t)(plan.tail_base - 1) * PW + pp] = 1.0;
+            bw[(size_t)(plan.rows - 1) * PW + pp] = 1.0;
+        }
     }
     // first tile -> LDS, second tile -> registers (in flight)
     double stage[CPT];
@@ -421,7 +430,7 @@ k_bary_mfma4(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
     for (int s = 0; s < KS; ++s) {
         unsigned code = kcode[4 * s + g];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bw + 16 * nt + c, PW);
+        for (int nt = 0; nt < NT; ++nt) B[nt][s] = code_weight(code, bwt + 16 * nt + c, PW);
     }
 
     double total[NT], cs[NT];

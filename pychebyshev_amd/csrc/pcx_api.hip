@@ -194,6 +194,22 @@ struct Scratch {
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; cap = 0; }
 };
 
+// RAII device buffer: freed on every exit path unless release() hands the pointer on
+struct DevBuf {
+    void *p = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) {
+        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
+        if (e != hipSuccess) { p = nullptr; return fail(PCX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+        return PCX_OK;
+    }
+    template <typename T> T *as() { return (T *)p; }
+    template <typename T> T *release() { T *q = (T *)p; p = nullptr; return q; }
+};
+
 // Host-pointer batches are processed in chunks so the staging buffers stay bounded.
 static const int64_t kChunkPoints = 1 << 23;
 // ... and, from two such pieces on, in 256 Ki-point pieces alternating between two streams
@@ -230,6 +246,14 @@ struct DerivedTensor {
     double *plain = nullptr;  // C-order tensor after the derivative passes (prod n doubles)
     double *frag = nullptr;   // MFMA A-fragment packing of `plain` (MT*KS*64 doubles) or NULL
     double **slot = nullptr;  // device table with the single entry `frag` (kernel's frag_tab)
+    uint64_t last_use = 0;    // handle clock at the last request (least-recently-used eviction)
+    void free_all() {
+        if (plain) (void)hipFree(plain);
+        if (frag) (void)hipFree(frag);
+        if (slot) (void)hipFree(slot);
+        plain = frag = nullptr;
+        slot = nullptr;
+    }
 };
 
 struct pcx_bary {
@@ -251,6 +275,8 @@ struct pcx_bary {
     int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
+    uint64_t clock = 0;              // bumped per request; entries used since `call_mark` are never evicted
+    uint64_t call_mark = 0;
     Scratch s_pts, s_out;
     hipStream_t stream2 = nullptr;   // second staging slot of the host-pointer pipeline (lazy)
     Scratch s_pts2, s_out2;
@@ -260,7 +286,8 @@ struct pcx_bary {
     Pinned pin;                      // zero-copy staging for small host-pointer batches
 };
 
-static const int kMaxSpecs = 64;
+static const int kMaxSpecs = 64;      // derivative specs evaluated by one launch (grid.z)
+static const int kCacheSpecs = 96;    // derivative tensors kept per handle besides the untransformed one
 
 // every k-step count up to 32 is instantiated: no padding of the folded K axis beyond 4;
 // 36..64 (one column tile per wave only: the B operands alone are up to 128 VGPRs) let two
@@ -283,10 +310,11 @@ static bool plan_mfma(const BaryDims &dm, BaryMfmaPlan &best) {
     long best_cost = 0;
     for (int split = std::max(0, dm.d - 2 * PCX_CODE_FIELDS); split < dm.d; ++split) {
         if (split > 2 * PCX_CODE_FIELDS) continue;  // head dims must fit the two words of a row code
-        long M = 1, K = 1;
-        for (int k = 0; k < split; ++k) M *= dm.n[k];
-        for (int k = split; k < dm.d; ++k) K *= dm.n[k];
+        long M = 1, K = 1, head_rows = 0, tail_rows = 0;
+        for (int k = 0; k < split; ++k) { M *= dm.n[k]; head_rows += dm.n[k]; }
+        for (int k = split; k < dm.d; ++k) { K *= dm.n[k]; tail_rows += dm.n[k]; }
         if (K > 256 || M > (1 << 24)) continue;
+        if (head_rows > PCX_MAX_PART_ROWS || tail_rows > PCX_MAX_PART_ROWS) continue;   // 8-bit code fields per table part
         int ks = pick_ks((int)K);
         if (ks < 0) continue;
         long mt = (M + 15) / 16;
@@ -295,28 +323,26 @@ static bool plan_mfma(const BaryDims &dm, BaryMfmaPlan &best) {
             found = true;
             best_cost = cost;
             best.split = split; best.M = (int)M; best.K = (int)K; best.MT = (int)mt; best.KS = ks;
+            best.tail_base = (int)head_rows + 1;
+            best.rows = dm.sum_n + 2;
         }
     }
     return found;
 }
 
 static size_t mfma4_lds_bytes(const BaryDims &dm, int ks) {
-    return ((size_t)8 * (dm.sum_n + 1) * 32 + (size_t)2 * ks * 64) * sizeof(double);
+    return ((size_t)8 * (dm.sum_n + 2) * 32 + (size_t)2 * ks * 64) * sizeof(double);
 }
 
 static size_t mfma_lds_bytes(const BaryDims &dm, int nt) {
-    return (size_t)4 * (dm.sum_n + 1) * 16 * nt * sizeof(double);
+    return (size_t)4 * (dm.sum_n + 2) * 16 * nt * sizeof(double);
 }
 
 extern "C" int pcx_bary_destroy(pcx_bary *h) {
     if (!h) return PCX_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    for (auto &kv : h->cache) {
-        if (kv.second.plain) (void)hipFree(kv.second.plain);
-        if (kv.second.frag) (void)hipFree(kv.second.frag);
-        if (kv.second.slot) (void)hipFree(kv.second.slot);
-    }
+    for (auto &kv : h->cache) kv.second.free_all();
     (void)hipFree(h->d_tab);
     h->s_partial.release();
     h->pin.release();
@@ -331,17 +357,23 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     return PCX_OK;
 }
 
+// Packs dt.plain into MFMA fragments; on failure dt.frag / dt.slot are released again.
 static int bary_pack(pcx_bary *h, DerivedTensor &dt) {
     if (!h->mfma_ok) return PCX_OK;
     const BaryMfmaPlan &p = h->plan;
     size_t cnt = (size_t)p.MT * p.KS * 64;
-    HIP_TRY(hipMalloc((void **)&dt.frag, cnt * sizeof(double)));
+    DevBuf frag, slot;
+    int rc = frag.alloc(cnt * sizeof(double));
+    if (rc) return rc;
     int blocks = (int)((cnt + 255) / 256);
-    hipLaunchKernelGGL(k_pack_fragments, dim3(blocks), dim3(256), 0, h->stream, dt.plain, dt.frag,
+    hipLaunchKernelGGL(k_pack_fragments, dim3(blocks), dim3(256), 0, h->stream, dt.plain, frag.as<double>(),
                        p.M, p.K, p.MT, p.KS);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMalloc((void **)&dt.slot, sizeof(double *)));
-    HIP_TRY(hipMemcpy(dt.slot, &dt.frag, sizeof(double *), hipMemcpyHostToDevice));
+    if ((rc = slot.alloc(sizeof(double *)))) return rc;
+    double *fp = frag.as<double>();
+    HIP_TRY(hipMemcpy(slot.p, &fp, sizeof(double *), hipMemcpyHostToDevice));
+    dt.frag = frag.release<double>();
+    dt.slot = slot.release<double *>();
     return PCX_OK;
 }
 
@@ -401,22 +433,31 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     h->lpp = lpp;
 
     // MFMA plan + row/k codes
-    h->mfma_ok = (sum_n <= PCX_MAX_SUM_N) && plan_mfma(h->dims, h->plan);
+    h->mfma_ok = plan_mfma(h->dims, h->plan);
     if (h->mfma_ok) {
         h->nt = (h->plan.KS > 32) ? 1 : 2;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->nt = 1;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->mfma_ok = false;
     }
+    // shapes no kernel covers fail here, at create, not at the first evaluation: the rows kernel
+    // keeps (256 / lpp) x sum_n weights in LDS
+    if (!h->mfma_ok && (size_t)(256 / h->lpp) * sum_n * sizeof(double) > 160 * 1024) {
+        int c_ = fail(PCX_ERR_UNSUPPORTED, "sum of node counts %ld too large for any kernel (MFMA plan: each of the "
+                      "head / tail parts <= %d rows and a tail product <= 256; row kernel: sum <= 5120)", sum_n, PCX_MAX_PART_ROWS);
+        pcx_bary_destroy(h);
+        return c_;
+    }
     h->mfma4_ok = h->mfma_ok && mfma4_lds_bytes(h->dims, h->plan.KS) <= 160 * 1024 &&
                   h->plan.KS <= 32 && h->plan.split <= PCX_CODE_FIELDS && d - h->plan.split <= PCX_CODE_FIELDS;
     if (h->mfma_ok) {
         const BaryMfmaPlan &p = h->plan;
-        const unsigned ones = (unsigned)sum_n;  // index of the all-ones table row
+        // all-ones rows: the last row of the head part (row codes) and of the tail part (k codes)
+        const unsigned ones_h = (unsigned)(p.tail_base - 1), ones_t = (unsigned)(p.rows - 1 - p.tail_base);
         std::vector<unsigned> rowcode((size_t)p.MT * 16), kcode((size_t)p.KS * 4);
         std::vector<unsigned> rowcode_hi(rowcode.size()), kcode_hi(kcode.size());
         h->wide = p.split > PCX_CODE_FIELDS || d - p.split > PCX_CODE_FIELDS;
         for (long m = 0; m < (long)p.MT * 16; ++m) {
-            unsigned f[2 * PCX_CODE_FIELDS] = {ones, ones, ones, ones, ones, ones, ones, ones};
+            unsigned f[2 * PCX_CODE_FIELDS] = {ones_h, ones_h, ones_h, ones_h, ones_h, ones_h, ones_h, ones_h};
             if (m < p.M) {
                 long rem = m;
                 for (int k = p.split - 1; k >= 0; --k) {
@@ -429,13 +470,13 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
             rowcode_hi[m] = f[4] | (f[5] << 8) | (f[6] << 16) | (f[7] << 24);
         }
         for (long kk = 0; kk < (long)p.KS * 4; ++kk) {
-            unsigned f[2 * PCX_CODE_FIELDS] = {ones, ones, ones, ones, ones, ones, ones, ones};
+            unsigned f[2 * PCX_CODE_FIELDS] = {ones_t, ones_t, ones_t, ones_t, ones_t, ones_t, ones_t, ones_t};
             if (kk < p.K) {
                 long rem = kk;
                 for (int k = d - 1; k >= p.split; --k) {
                     int i = (int)(rem % h->dims.n[k]);
                     rem /= h->dims.n[k];
-                    f[k - p.split] = (unsigned)(h->dims.off[k] + i);
+                    f[k - p.split] = (unsigned)(h->dims.off[k] - h->dims.off[p.split] + i);   // relative to the tail part
                 }
             }
             kcode[kk] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
@@ -555,14 +596,36 @@ static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **ou
             key[k] = deriv[k];
         }
     auto it = h->cache.find(key);
-    if (it != h->cache.end()) { *out = &it->second; return PCX_OK; }
-    if (h->cache.size() > 64) return fail(PCX_ERR_UNSUPPORTED, "more than 64 distinct derivative specs cached on one handle");
+    if (it != h->cache.end()) {
+        it->second.last_use = ++h->clock;
+        *out = &it->second;
+        return PCX_OK;
+    }
+    // The cache holds the untransformed tensor plus up to kCacheSpecs derivative tensors; beyond
+    // that the least recently used one that the current call has not asked for is dropped.
+    // Kernels reading it may still be queued (on any stream of a _dev caller): drain the device first.
+    if (h->cache.size() > (size_t)kCacheSpecs) {
+        auto victim = h->cache.end();
+        for (auto c = h->cache.begin(); c != h->cache.end(); ++c) {
+            bool is_base = true;
+            for (int v : c->first) is_base = is_base && v == 0;
+            if (is_base || c->second.last_use > h->call_mark) continue;
+            if (victim == h->cache.end() || c->second.last_use < victim->second.last_use) victim = c;
+        }
+        if (victim == h->cache.end())
+            return fail(PCX_ERR_UNSUPPORTED, "more than %d distinct derivative specs in one call", kCacheSpecs);
+        HIP_TRY(hipDeviceSynchronize());
+        if (!h->tab_host.empty()) h->tab_host.clear();      // the multi-spec table may name the victim
+        victim->second.free_all();
+        h->cache.erase(victim);
+    }
 
     DerivedTensor &base = h->cache[std::vector<int>(d, 0)];
-    double *cur = nullptr, *tmp = nullptr;
-    HIP_TRY(hipMalloc((void **)&cur, h->total * sizeof(double)));
-    if (hipMalloc((void **)&tmp, h->total * sizeof(double)) != hipSuccess) { (void)hipFree(cur); return fail(PCX_ERR_NOMEM, "hipMalloc failed"); }
-    HIP_TRY(hipMemcpyAsync(cur, base.plain, h->total * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    DevBuf cur, tmp;
+    int rc = cur.alloc(h->total * sizeof(double));
+    if (rc) return rc;
+    if ((rc = tmp.alloc(h->total * sizeof(double)))) return rc;
+    HIP_TRY(hipMemcpyAsync(cur.p, base.plain, h->total * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     // barycentric.py:982-989: dims descending, order[k] passes each
     for (int k = d - 1; k >= 0; --k) {
         long outer = 1, inner = 1;
@@ -570,18 +633,18 @@ static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **ou
         for (int q = k + 1; q < d; ++q) inner *= h->dims.n[q];
         for (int r = 0; r < key[k]; ++r) {
             int blocks = (int)((h->total + 255) / 256);
-            hipLaunchKernelGGL(k_mode_product, dim3(blocks), dim3(256), 0, h->stream, cur, tmp,
+            hipLaunchKernelGGL(k_mode_product, dim3(blocks), dim3(256), 0, h->stream, cur.as<double>(), tmp.as<double>(),
                                h->d_diff + h->doff[k], outer, h->dims.n[k], inner);
-            std::swap(cur, tmp);
+            std::swap(cur.p, tmp.p);
         }
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));
-    (void)hipFree(tmp);
     DerivedTensor dt;
-    dt.plain = cur;
-    int rc = bary_pack(h, dt);
-    if (rc) { (void)hipFree(cur); return rc; }
+    dt.plain = cur.as<double>();
+    if ((rc = bary_pack(h, dt))) return rc;          // cur still owns the tensor: freed on this path
+    (void)cur.release<double>();
+    dt.last_use = ++h->clock;
     auto ins = h->cache.emplace(key, dt);
     *out = &ins.first->second;
     return PCX_OK;
@@ -734,6 +797,7 @@ extern "C" int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t
     if (N > 0 && (!d_pts || !d_out)) return fail(PCX_ERR_INVALID, "NULL device buffer");
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
+    h->call_mark = h->clock;
     DerivedTensor *dt = nullptr;
     int rc = bary_get_tensor(h, deriv, &dt);
     if (rc) return rc;
@@ -747,10 +811,26 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
                           double *out) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
     if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
-    if (m > kMaxSpecs) return fail(PCX_ERR_UNSUPPORTED, "more than %d derivative specs in one call", kMaxSpecs);
     if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (m > kMaxSpecs) {
+        // more specs than one launch takes (the reference has no limit: a gradient plus full
+        // Hessian in 10-D is 65): groups of kMaxSpecs, each into its columns of `out`
+        if (!derivs) return fail(PCX_ERR_INVALID, "derivs is NULL");
+        const int d0 = h->dims.d;
+        std::vector<double> part;
+        for (int s0 = 0; s0 < m; s0 += kMaxSpecs) {
+            const int mc = std::min(kMaxSpecs, m - s0);
+            part.resize((size_t)N * mc);
+            int rc = bary_eval_host(h, pts, N, derivs + (size_t)s0 * d0, mc, part.data());
+            if (rc) return rc;
+            for (int64_t i = 0; i < N; ++i)
+                memcpy(out + (size_t)i * m + s0, part.data() + (size_t)i * mc, (size_t)mc * sizeof(double));
+        }
+        return PCX_OK;
+    }
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
+    h->call_mark = h->clock;
     const int d = h->dims.d;
     std::vector<DerivedTensor *> dts(m);
     for (int s = 0; s < m; ++s) {
@@ -841,6 +921,7 @@ extern "C" int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, dou
     if (!h || !tensor_out) return fail(PCX_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
+    h->call_mark = h->clock;
     DerivedTensor *dt = nullptr;
     int rc = bary_get_tensor(h, deriv, &dt);
     if (rc) return rc;
@@ -848,11 +929,6 @@ extern "C" int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, dou
     HIP_TRY(hipMemcpy(tensor_out, dt->plain, h->total * sizeof(double), hipMemcpyDeviceToHost));
     return PCX_OK;
 }
-
-struct DevBufLite {
-    void *p = nullptr;
-    ~DevBufLite() { if (p) (void)hipFree(p); }
-};
 
 extern "C" int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const double *tensor,
                                         int axis, const double *vec, double *out) {
@@ -867,7 +943,7 @@ extern "C" int pcx_tensor_contract_axis(int device, int d, const int32_t *n_node
     const int na = n_nodes[axis];
     int rc = use_device(device);
     if (rc) return rc;
-    DevBufLite din, dvec, dout;
+    DevBuf din, dvec, dout;
     HIP_TRY(hipMalloc(&din.p, (size_t)outer * na * inner * sizeof(double)));
     HIP_TRY(hipMalloc(&dvec.p, (size_t)na * sizeof(double)));
     HIP_TRY(hipMalloc(&dout.p, (size_t)outer * inner * sizeof(double)));
@@ -1006,8 +1082,20 @@ static int spline_eval_host(pcx_spline *h, const double *pts, int64_t N, const i
                             double *out) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
     if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
-    if (m > kMaxSpecs) return fail(PCX_ERR_UNSUPPORTED, "more than %d derivative specs in one call", kMaxSpecs);
     if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (m > kMaxSpecs) {      // groups of kMaxSpecs specs, each into its columns of `out`
+        if (!derivs) return fail(PCX_ERR_INVALID, "derivs is NULL");
+        std::vector<double> part;
+        for (int s0 = 0; s0 < m; s0 += kMaxSpecs) {
+            const int mc = std::min(kMaxSpecs, m - s0);
+            part.resize((size_t)N * mc);
+            int rc = spline_eval_host(h, pts, N, derivs + (size_t)s0 * h->sd.d, mc, part.data());
+            if (rc) return rc;
+            for (int64_t i = 0; i < N; ++i)
+                memcpy(out + (size_t)i * m + s0, part.data() + (size_t)i * mc, (size_t)mc * sizeof(double));
+        }
+        return PCX_OK;
+    }
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
     const int d = h->sd.d;
@@ -1027,6 +1115,7 @@ static int spline_eval_host(pcx_spline *h, const double *pts, int64_t N, const i
             if (counts[i] == 0) continue;
             pcx_bary *pc = h->pieces[i];
             std::lock_guard<std::mutex> plk(pc->mu);
+            pc->call_mark = pc->clock;
             std::vector<DerivedTensor *> dts(m);
             for (int s = 0; s < m; ++s) {
                 rc = bary_get_tensor(pc, derivs ? derivs + (size_t)s * d : nullptr, &dts[s]);
@@ -1174,6 +1263,13 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
             h->gi.rank[k] = ranks[k];
             h->gi.coff[k] = coff[k];
             h->gi.nmax = std::max(h->gi.nmax, (int)n_nodes[k]);
+        }
+        // the generic kernel keeps 2 rmax + nmax doubles per wave in LDS (4 waves per workgroup)
+        if ((size_t)4 * (2 * h->gi.rmax + h->gi.nmax) * sizeof(double) > 160 * 1024) {
+            const int rm = h->gi.rmax, nm = h->gi.nmax;
+            delete h;
+            return fail(PCX_ERR_UNSUPPORTED, "TT rank %d with %d nodes exceeds the generic kernel's LDS budget "
+                        "(2 rank + nodes <= 5120)", rm, nm);
         }
         h->gi.rank[d] = ranks[d];
         hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
@@ -1500,16 +1596,6 @@ extern "C" int pcx_tt_stream(pcx_tt *h, void **stream) {
 // ---------------------------------------------------------------------------------
 // TT-Cross build steps
 // ---------------------------------------------------------------------------------
-struct DevBuf {
-    void *p = nullptr;
-    ~DevBuf() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) {
-        hipError_t e = hipMalloc(&p, bytes ? bytes : 8);
-        if (e != hipSuccess) { p = nullptr; return fail(PCX_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
-        return PCX_OK;
-    }
-    template <typename T> T *as() { return (T *)p; }
-};
 
 extern "C" int pcx_tt_value_to_coeff_core(int device, const double *value_core, int rl, int n, int rr,
                                           double *coeff_core) {

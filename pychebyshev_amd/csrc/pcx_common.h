@@ -10,9 +10,12 @@
 
 typedef double pcx_d4 __attribute__((ext_vector_type(4)));
 
-// Row codes are 4 x 8-bit row indices into the per-wave weight table held in LDS
-// ([sum_n + 1][points] doubles; the extra last row is all ones and pads unused fields).
-#define PCX_MAX_SUM_N 254
+// Row / k codes are 4 x 8-bit row indices into the per-wave weight table held in LDS.  The
+// table has two parts, each closed by a row of ones that pads unused fields:
+//   [head dims 0..split) rows][ones][tail dims split..d) rows][ones]      (sum_n + 2 rows)
+// row codes index the head part from 0, k codes the tail part from plan.tail_base, so each
+// part may hold up to PCX_MAX_PART_ROWS weight rows (e.g. 64^4 = 192 + 64).
+#define PCX_MAX_PART_ROWS 255
 #define PCX_CODE_FIELDS 4
 
 // ---- barycentric kernel parameters (passed by value -> kernarg / SGPRs) ----------
@@ -31,6 +34,8 @@ struct BaryMfmaPlan {
     int K;    // prod n[split:d]
     int MT;   // row tiles of 16 covering M
     int KS;   // k-steps of 4 run by the kernel instantiation (KS*4 >= K)
+    int tail_base;  // first table row of the tail part (= sum of head n + 1)
+    int rows;       // table rows (= sum_n + 2)
 };
 
 // ---- tensor-train kernel parameters ---------------------------------------------

@@ -173,7 +173,10 @@ def test_derivative_tensor_kernel_is_bit_identical_to_oracle(bs5d, oracle_mod):
     ((3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2), [[0, 1]] * 13),   # d = 13: wide, 8-dim tail K = 128... head 5
     ((130, 2), [[0.0, 1.0], [0.0, 1.0]]),                  # last-dim n > 128 with K too large -> split picks head
     ((2, 200), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 200: single-column-tile kernel, 52 k-steps
-    ((2, 300), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 300 > 256 and sum_n > 254: rows kernel
+    ((2, 300), [[0.0, 1.0], [0.0, 1.0]]),                  # K = 300 > 256: no MFMA plan, rows kernel
+    ((100, 90, 70), [[0, 1], [-2, -1], [5, 9]]),           # sum_n = 260: head part 190 rows + tail part 70 rows
+    ((200, 80), [[0.0, 1.0], [0.0, 1.0]]),                 # sum_n = 280: 144 KB weight table, one column tile per wave
+    ((250, 250), [[0.0, 1.0], [0.0, 1.0]]),                # sum_n = 500: the table no longer fits LDS -> rows kernel
 ])
 def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     rng = np.random.default_rng(sum(shape))
@@ -195,9 +198,9 @@ def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     info = _lib.i32(np.zeros(6))
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
-    if shape == (2, 300):
+    if shape in ((2, 300), (250, 250)):
         assert info[0] == 1, "expected the rows kernel for this shape"
-    elif d >= 8 or shape in ((2, 200), (14, 13, 15), (16,) * 4):
+    elif d >= 8 or shape in ((2, 200), (14, 13, 15), (16,) * 4, (100, 90, 70), (200, 80)):
         assert info[0] == 2, "expected the MFMA kernel for this shape"
 
 
@@ -542,5 +545,128 @@ def test_fuzz_random_tensor_shapes_against_oracle(oracle_mod):
             spec[k] = int(rng.integers(1, 3))
         ref = oracle_mod.bary_eval_batch(om, pts, spec)
         got = c.vectorized_eval_batch(pts, spec)
-        scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(T))))
-        assert np.max(np.abs(got - ref)) <= 1e-11 * scale, (case, shape, spec, npts)
+        # The bar is 1e-12 normwise.  What the kernel contracts is the derivative tensor T' = T x_k D^order
+        # (bit-identical to the oracle's, test_derivative_tensor_kernel_is_bit_identical_to_oracle), so the
+        # rounding of a different summation order is bounded by eps * max|T'| * (Lebesgue constants), not by
+        # max|ref|: for a batch whose values all happen to be small (one random point) max|T'| is the scale.
+        Td = T
+        for k in range(d):
+            for _ in range(spec[k]):
+                Td = np.moveaxis(np.moveaxis(Td, k, -1) @ c.diff_matrices[k].T, -1, k)
+        scale = float(np.max(np.abs(ref)))
+        if npts < 31:
+            scale = max(scale, float(np.max(np.abs(Td))))
+        assert np.max(np.abs(got - ref)) <= 1e-12 * scale, (case, shape, spec, npts)
+
+
+# ------------------------------------------------------------------ limits lifted in round 2
+def test_four_dimensions_at_the_reference_auto_n_cap(oracle_mod):
+    """64^4 (the reference's auto-N cap max_n = 64, barycentric.py:349): sum_n = 256 used to
+    fall to the row kernel (8-bit row codes over ONE table); the head / tail table parts keep it
+    on the MFMA kernel.  134 MB tensor, few points (the oracle walks all of it per point)."""
+    rng = np.random.default_rng(64)
+    shape = (64, 64, 64, 64)
+    T = rng.standard_normal(shape)
+    dom = [[-1.0, 1.0], [0.0, 2.0], [10.0, 11.0], [-3.0, 5.0]]
+    c = ChebyshevApproximation.from_values(T, 4, dom, list(shape))
+    pts = np.column_stack([rng.uniform(lo, hi, 96) for lo, hi in dom])
+    pts[0] = [c.nodes[k][5 * k + 1] for k in range(4)]              # a grid point: the tensor entry itself
+    om = _oracle_model(oracle_mod, c)
+    got = c.vectorized_eval_batch(pts, [0, 0, 0, 0])
+    assert got[0] == T[1, 6, 11, 16]
+    assert_parity(got, oracle_mod.bary_eval_batch(om, pts, [0, 0, 0, 0]), 1e-12, "64^4 value")
+    info = _lib.i32(np.zeros(6))
+    m = c._model()
+    m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
+    assert info[0] == 2, "64^4 must run on the MFMA kernel"
+
+
+def test_more_derivative_specs_than_one_launch_or_the_cache_holds(oracle_mod):
+    """The reference has no limit on distinct derivative specs.  Gradient + full Hessian in 10-D is
+    65 specs (one launch takes 64); all 243 order <= 2 specs of a 5-D model exceed the per-handle
+    cache (96 derivative tensors): least-recently-used tensors are dropped and rebuilt."""
+    rng = np.random.default_rng(65)
+    d = 10
+    T = rng.standard_normal((3,) * d)
+    dom = [[0.0, 1.0]] * d
+    c = ChebyshevApproximation.from_values(T, d, dom, [3] * d)
+    specs = [[0] * d]
+    for i in range(d):
+        specs.append([1 if k == i else 0 for k in range(d)])
+    for i in range(d):
+        for j in range(i, d):
+            s = [0] * d
+            s[i] += 1
+            s[j] += 1
+            specs.append(s)
+    assert len(specs) == 66
+    pts = rng.uniform(0, 1, (7, d))
+    om = _oracle_model(oracle_mod, c)
+    got = c.vectorized_eval_multi_batch(pts, specs)                  # 66 > 64: two launches, one call
+    assert got.shape == (7, 66)
+    for j, s in enumerate(specs):
+        ref = oracle_mod.bary_eval_batch(om, pts, s)
+        assert np.max(np.abs(got[:, j] - ref)) <= 1e-12 * max(np.max(np.abs(ref)), 1.0), s
+    one = c.vectorized_eval_multi(list(pts[3]), specs)
+    assert np.array_equal(np.array(one), got[3])
+
+    import itertools
+    T5 = rng.standard_normal((4, 5, 3, 4, 3))
+    dom5 = [[-1.0, 1.0], [0.0, 3.0], [2.0, 2.5], [-4.0, 0.0], [1.0, 9.0]]
+    c5 = ChebyshevApproximation.from_values(T5, 5, dom5, [4, 5, 3, 4, 3])
+    om5 = _oracle_model(oracle_mod, c5)
+    p5 = np.column_stack([rng.uniform(lo, hi, 33) for lo, hi in dom5])
+    all_specs = [list(s) for s in itertools.product(range(3), repeat=5)]       # 243 specs
+    first = {}
+    for s in all_specs:                                            # one by one: fills and overflows the cache
+        first[tuple(s)] = c5.vectorized_eval_batch(p5, s)
+    for s in all_specs[:40] + all_specs[-5:]:                      # the early ones were evicted: rebuilt, same bits
+        again = c5.vectorized_eval_batch(p5, s)
+        assert np.array_equal(again, first[tuple(s)]), s
+    for s in all_specs[::17]:
+        ref = oracle_mod.bary_eval_batch(om5, p5, s)
+        assert np.max(np.abs(first[tuple(s)] - ref)) <= 1e-12 * max(np.max(np.abs(ref)), 1e-300), s
+    big = c5.vectorized_eval_multi_batch(p5, all_specs)            # 243 specs in one call: 4 launches
+    for j, s in enumerate(all_specs):
+        assert np.array_equal(big[:, j], first[tuple(s)]), s
+
+
+def test_shapes_no_kernel_covers_fail_at_create():
+    """Create-time, not first-evaluation-time, errors: a shape outside both the MFMA
+    plan (tail product > 256) and the row kernel's LDS budget (sum of nodes > 5120)."""
+    lib = _lib.load()
+    n = _lib.i32([3000, 3000])
+    z = _lib.f64(np.zeros(6000))
+    zz = _lib.f64(np.zeros(2 * 3000 * 3000))
+    h = ctypes.c_void_p()
+    rc = lib.pcx_bary_create(0, 2, _lib.p_i32(n), _lib.p_f64(z), _lib.p_f64(z), _lib.p_f64(zz), _lib.p_f64(zz),
+                             ctypes.byref(h))
+    assert rc == _lib.PCX_ERR_UNSUPPORTED and b"too large" in lib.pcx_last_error()
+    # TT: the generic kernel's per-wave LDS slice is 2 rank + nodes doubles
+    ranks = _lib.i32([1, 3000, 1])
+    nn = _lib.i32([2, 2])
+    lo, hi = _lib.f64([0, 0]), _lib.f64([1, 1])
+    cores = _lib.f64(np.zeros(2 * 3000 * 2))
+    rc = lib.pcx_tt_create(0, 2, _lib.p_i32(nn), _lib.p_i32(ranks), _lib.p_f64(lo), _lib.p_f64(hi), _lib.p_f64(cores),
+                           None, ctypes.byref(h))
+    assert rc == _lib.PCX_ERR_UNSUPPORTED and b"LDS" in lib.pcx_last_error()
+
+
+def test_derivative_order_rules_of_the_reference_on_the_device(bs5d, oracle_mod):
+    """eval() keeps the scalar path's order <= 2 rule (barycentric.py:717-787) while the vectorized
+    methods take any order (the hoisted tensor passes have no limit, :951-990); get_derivative_id
+    checks the range [0, max_derivative_order] (:1173-1217)."""
+    c, g = bs5d
+    pts = g["points"][:200]
+    om = _oracle_model(oracle_mod, c)
+    third = [3, 0, 0, 0, 0]
+    ref = oracle_mod.bary_eval_batch(om, pts, third)
+    assert_parity(c.vectorized_eval_batch(pts, third), ref, 1e-12, "third derivative, batch")
+    assert abs(c.vectorized_eval(list(pts[7]), third) - ref[7]) <= 1e-12 * np.max(np.abs(ref))
+    with pytest.raises(ValueError, match="not supported"):
+        c.eval(list(pts[7]), third)
+    with pytest.raises(ValueError, match="out of range"):
+        c.get_derivative_id(third)
+    c3 = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES, max_derivative_order=3)
+    did = c3.get_derivative_id(third)
+    assert np.array_equal(c3.vectorized_eval_batch(pts, derivative_id=did), c.vectorized_eval_batch(pts, third))

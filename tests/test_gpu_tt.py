@@ -419,7 +419,7 @@ def test_fuzz_random_tt_models_against_oracle(oracle_mod):
         ref = oracle_mod.tt_eval_batch(cores, dom, pts, dim_order=order)
         got = tt.eval_batch(pts)
         scale = max(float(np.max(np.abs(ref))), 1e-300)
-        assert np.max(np.abs(got - ref)) <= 2e-12 * scale, (case, d, ranks, n, order, npts)
+        assert np.max(np.abs(got - ref)) <= 1e-12 * scale, (case, d, ranks, n, order, npts)   # the stated bar, normwise
 
 
 def test_svd_and_cross_builds_agree_and_hit_the_closed_form():
