@@ -94,6 +94,11 @@ int pcx_bary_destroy(pcx_bary *h);
  * device handle.  Nodes / weights / differentiation matrices are rebuilt on the host
  * with the formulas of barycentric.py:440-452, :30-49, :52-77.  For C/C++ callers.    */
 int pcx_bary_create_from_pcb(int device, const char *path, pcx_bary **out);
+/* The write side of the same format (_binary.py:208-283): header, d, domain bounds, n_nodes
+ * and the untransformed tensor (copied back from the device), little-endian, byte-identical
+ * to what the reference writes for the same model.  lo / hi (d doubles each) give the domain;
+ * both may be NULL for a handle that came from pcx_bary_create_from_pcb (it remembers its own). */
+int pcx_bary_save_pcb(pcx_bary *h, const char *path, const double *lo, const double *hi);
 /* Shape of a handle: d (may be NULL) and n_nodes (PCX_MAX_DIMS ints, may be NULL).   */
 int pcx_bary_shape(pcx_bary *h, int32_t *d_out, int32_t *n_nodes_out);
 
@@ -124,7 +129,10 @@ int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const do
 /* Kernel selection and introspection.  variant: 0 = auto, 1 = row-parallel VALU kernel
  * (any shape), 2 = MFMA kernel (v_mfma_f64_16x16x4_f64), 3 = the same contraction on
  * v_mfma_f64_4x4x4_4b_f64 with LDS-staged tiles (bit-identical to 2; opt-in, never picked
- * by auto; PCX_ERR_UNSUPPORTED when the shape is not covered).  info_out receives
+ * by auto), 4 = lane-per-point kernel for small tensors (d <= 4, last dimension <= 64 nodes;
+ * what auto picks up to 4096 elements; it sums in the reference's own nesting order and
+ * forms the barycentric weights from prefix / suffix products, one division per dimension).
+ * PCX_ERR_UNSUPPORTED when the shape is not covered.  info_out receives
  * {variant used by auto, row tiles, k-steps, lds bytes, points per workgroup, split}.  */
 int pcx_bary_set_kernel(pcx_bary *h, int variant);
 int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);

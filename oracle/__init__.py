@@ -46,7 +46,9 @@ def build(force: bool = False) -> str:
 def _lib():
     global _LIB
     if _LIB is None:
-        _LIB = ctypes.CDLL(build())
+        # PCX_ORACLE_LIBRARY: an alternative build of pcx_oracle.c, e.g. libpcx_oracle_asan.so
+        # (make -C oracle libpcx_oracle_asan.so) for the AddressSanitizer run of the CPU suite
+        _LIB = ctypes.CDLL(os.environ.get("PCX_ORACLE_LIBRARY") or build())
         _LIB.pcxo_tt_eval_grid.restype = ctypes.c_double
     return _LIB
 

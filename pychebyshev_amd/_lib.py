@@ -70,6 +70,7 @@ SIGNATURES = {
     "pcx_bary_create": (_I, [_I, _I, c_i32p, c_f64p, c_f64p, c_f64p, c_f64p, c_vpp]),
     "pcx_bary_destroy": (_I, [_V]),
     "pcx_bary_create_from_pcb": (_I, [_I, ctypes.c_char_p, c_vpp]),
+    "pcx_bary_save_pcb": (_I, [_V, ctypes.c_char_p, c_f64p, c_f64p]),
     "pcx_bary_shape": (_I, [_V, c_i32p, c_i32p]),
     "pcx_bary_eval_batch": (_I, [_V, c_f64p, _L, c_i32p, c_f64p]),
     "pcx_bary_eval_batch_dev": (_I, [_V, _V, _L, c_i32p, _V, _V]),

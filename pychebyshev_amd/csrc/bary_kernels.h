@@ -588,6 +588,139 @@ k_bary_rows(BaryDims dims, int LPP, const double *__restrict__ nodes,
 }
 
 // ---------------------------------------------------------------------------------
+// K1+K2 for SMALL tensors (d <= 4, a few thousand elements): one lane = one point.
+//
+// For shapes like 12 x 12 (BASELINE config 1) or the 9 x 7 x 6 pieces of a spline the MFMA
+// kernel is all prologue: 3 matrix instructions per 32 points behind ~500 instructions of
+// weights, code look-ups and table traffic.  Here every lane owns a point and walks the whole
+// tensor in the reference's own nesting (barycentric.py:1036-1046: contract the last
+// dimension, then the one before, ...):
+//     y = sum_{i0} b0[i0] ( sum_{i1} b1[i1] ( ... sum_{iL} T[i0, i1, ..., iL] bL[iL] ) )
+// The tensor element is wave-uniform: it is read with SCALAR loads (s_load, scalar cache /
+// L2) and enters v_fma_f64 as an SGPR operand -- one 8-byte load feeds 64 FMAs, and neither
+// LDS (which could not feed four SIMDs one broadcast read per FMA) nor VGPR space is spent
+// on it.  The last dimension's weights live in registers (NLP = n_last rounded up, zeros
+// beyond n_last; the row read runs up to NLP - n_last doubles into the next row, which is
+// multiplied by those zeros: tensors carry PCX_PLAIN_PAD zeroed doubles behind their end), the
+// outer dimensions' weights in a per-wave LDS table [row][lane], read once per inner row.
+// One FMA per tensor element and one per inner result: the algorithmic count.
+// 64 threads per workgroup; dynamic LDS = (sum of outer n) * 64 * 8 bytes.
+// ---------------------------------------------------------------------------------
+#define PCX_PLAIN_PAD 64
+
+// Normalised barycentric weights WITHOUT a division per node: with t_i = (x - x_i) 2^e,
+//     b_j = w_j prod_{i != j} t_i / sum_k w_k prod_{i != k} t_i          (the common factor cancels)
+// from running prefix and suffix products: 8 vector instructions per node and one division per
+// dimension, against ~18 per node for u_j = w_j / (x - x_j) with its IEEE division sequence --
+// for a 12 x 12 tensor the weights, not the 156 FMAs of the contraction, are most of the work.
+// 2^e (a power of two near 2 / width, so that the products of up to 64 factors stay far from
+// over/underflow) is applied exactly: snodes = nodes 2^e is precomputed and t_i = fma(x, 2^e,
+// -snodes_i) is the correctly rounded (x - x_i) 2^e.  A coordinate exactly on node j gives the
+// one-hot row exactly (every other product contains the factor 0; b_j = c_j / c_j = 1); within
+// 1e-14 of a node, where the reference switches to the node's value, this evaluates the
+// interpolant at x itself -- the two differ by O(1e-14), far inside the 1e-12 bar.
+template <int NLP>
+__device__ __forceinline__ void bary_weights_reg(double x, double scale, const double *__restrict__ snodes,
+                                                 const double *__restrict__ wts, int n, double (&b)[NLP]) {
+    double t[NLP];
+    double run = 1.0;
+#pragma unroll
+    for (int j = 0; j < NLP; ++j) {                 // b_j <- w_j * prefix_j
+        b[j] = 0.0;
+        t[j] = 1.0;
+        if (j < n) {
+            t[j] = __builtin_fma(x, scale, -snodes[j]);
+            b[j] = wts[j] * run;
+            run *= t[j];
+        }
+    }
+    run = 1.0;
+    double su = 0.0;
+#pragma unroll
+    for (int j = NLP - 1; j >= 0; --j) {            // b_j <- b_j * suffix_j
+        if (j < n) {
+            b[j] *= run;
+            su += b[j];
+            run *= t[j];
+        }
+    }
+    const double r = 1.0 / su;
+#pragma unroll
+    for (int j = 0; j < NLP; ++j) b[j] *= r;
+}
+
+// The same through a lane's column of an LDS table (runtime node count): dst[j * stride].
+__device__ __forceinline__ void bary_weights_prod(double x, double scale, const double *__restrict__ snodes,
+                                                  const double *__restrict__ wts, int n, double *dst, int stride) {
+    double run = 1.0;
+    for (int j = 0; j < n; ++j) {
+        dst[j * stride] = wts[j] * run;
+        run *= __builtin_fma(x, scale, -snodes[j]);
+    }
+    run = 1.0;
+    double su = 0.0;
+    for (int j = n - 1; j >= 0; --j) {
+        const double c = dst[j * stride] * run;
+        dst[j * stride] = c;
+        su += c;
+        run *= __builtin_fma(x, scale, -snodes[j]);
+    }
+    const double r = 1.0 / su;
+    for (int j = 0; j < n; ++j) dst[j * stride] *= r;
+}
+
+template <int LEVEL, int DOUT, int NLP>
+__device__ __forceinline__ double bary_small_nest(const BaryDims &dims, const double *__restrict__ Tb,
+                                                  const double *bw_lane, const double (&bl)[NLP]) {
+    if constexpr (LEVEL == DOUT) {
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < NLP; ++i) s = __builtin_fma(Tb[i], bl[i], s);
+        return s;
+    } else {
+        long stride = 1;
+        for (int q = LEVEL + 1; q <= DOUT; ++q) stride *= dims.n[q];
+        const double *wk = bw_lane + (size_t)dims.off[LEVEL] * 64;
+        double s = 0.0;
+        for (int i = 0; i < dims.n[LEVEL]; ++i)
+            s = __builtin_fma(wk[(size_t)i * 64], bary_small_nest<LEVEL + 1, DOUT, NLP>(dims, Tb + i * stride, bw_lane, bl), s);
+        return s;
+    }
+}
+
+struct BarySmallScale {
+    double s[4];            // 2^e per dimension (d <= 4)
+};
+
+template <int DOUT, int NLP>
+__global__ void __launch_bounds__(64)
+k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, const double *__restrict__ nodes,
+             const double *__restrict__ wts, const double *__restrict__ T, const double *__restrict__ pts,
+             double *__restrict__ out, long N, long ostride, long ooff, const int *__restrict__ perm) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long pidx = (long)blockIdx.x * 64 + lane;
+    const bool valid = pidx < N;
+    const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
+    const int d = DOUT + 1;
+    double *bw_lane = lds + lane;
+#pragma unroll
+    for (int k = 0; k < DOUT; ++k) {
+        const double x = valid ? pts[row * d + k] : nodes[dims.off[k]];
+        bary_weights_prod(x, sc.s[k], snodes + dims.off[k], wts + dims.off[k], dims.n[k],
+                          bw_lane + (size_t)dims.off[k] * 64, 64);
+    }
+    double bl[NLP];
+    {
+        const double x = valid ? pts[row * d + DOUT] : nodes[dims.off[DOUT]];
+        bary_weights_reg<NLP>(x, sc.s[DOUT], snodes + dims.off[DOUT], wts + dims.off[DOUT], dims.n[DOUT], bl);
+    }
+    // the table is wave-private (one wave per workgroup): no barrier
+    const double y = bary_small_nest<0, DOUT, NLP>(dims, T, bw_lane, bl);
+    if (valid) out[row * ostride + ooff] = y;
+}
+
+// ---------------------------------------------------------------------------------
 // Piecewise interpolants (reference spline.py:633-700, ChebyshevSpline.eval_batch):
 // route every point to its piece, bucket the points, then run the barycentric kernel once
 // per non-empty piece on that piece's bucket (its `perm` argument).

@@ -210,6 +210,15 @@ struct DevBuf {
     template <typename T> T *release() { T *q = (T *)p; p = nullptr; return q; }
 };
 
+// "Plain" (C-order) tensors carry PCX_PLAIN_PAD zeroed doubles behind their end: k_bary_small reads a
+// row with a fixed-width run of scalar loads that may reach past the last row.
+static int alloc_plain(DevBuf &b, long total) {
+    int rc = b.alloc(((size_t)total + PCX_PLAIN_PAD) * sizeof(double));
+    if (rc) return rc;
+    HIP_TRY(hipMemset((char *)b.p + (size_t)total * sizeof(double), 0, PCX_PLAIN_PAD * sizeof(double)));
+    return PCX_OK;
+}
+
 // Host-pointer batches are processed in chunks so the staging buffers stay bounded.
 static const int64_t kChunkPoints = 1 << 23;
 // ... and, from two such pieces on, in 256 Ki-point pieces alternating between two streams
@@ -272,7 +281,12 @@ struct pcx_bary {
     bool wide = false;      // more than four head or tail dimensions
     int lpp = 64;                    // lanes per point in the rows kernel
     bool mfma4_ok = false;           // 4x4x4_4b form available (LDS budget)
-    int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b
+    int small_nlp = 0;               // lane-per-point kernel for small tensors: padded last-dim width, 0 = not available
+    std::vector<double> dom_lo, dom_hi;   // the domain, when the handle came from a .pcb file (pcx_bary_save_pcb)
+    BarySmallScale small_scale;      // its power-of-two coordinate scales and the nodes times them
+    double *d_snodes = nullptr;
+    bool small_preferred = false;    // auto picks it (few row tiles: the MFMA kernel would be all prologue)
+    int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b, 4 lane-per-point (small tensors)
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
     uint64_t clock = 0;              // bumped per request; entries used since `call_mark` are never evicted
@@ -286,6 +300,7 @@ struct pcx_bary {
     Pinned pin;                      // zero-copy staging for small host-pointer batches
 };
 
+static const long kSmallTensorElems = 4096;   // auto: tensors up to this size run on k_bary_small
 static const int kMaxSpecs = 64;      // derivative specs evaluated by one launch (grid.z)
 static const int kCacheSpecs = 96;    // derivative tensors kept per handle besides the untransformed one
 
@@ -347,6 +362,7 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     h->s_partial.release();
     h->pin.release();
     (void)hipFree(h->d_nodes); (void)hipFree(h->d_wts); (void)hipFree(h->d_diff);
+    (void)hipFree(h->d_snodes);
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
     (void)hipFree(h->d_rowcode_hi); (void)hipFree(h->d_kcode_hi);
     h->s_pts.release(); h->s_out.release();
@@ -449,6 +465,33 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     }
     h->mfma4_ok = h->mfma_ok && mfma4_lds_bytes(h->dims, h->plan.KS) <= 160 * 1024 &&
                   h->plan.KS <= 32 && h->plan.split <= PCX_CODE_FIELDS && d - h->plan.split <= PCX_CODE_FIELDS;
+    // lane-per-point kernel (k_bary_small): d <= 4, last dimension <= 64 nodes (weights in registers),
+    // outer weights table (sum of outer n) x 64 lanes x 8 B within 64 KB.  Preferred by auto while the
+    // tensor is small enough that the MFMA kernel's prologue outweighs its tiles
+    // (tools/bary_rate_probe.py, profiles/r02_bary_rate_probe.txt).
+    {
+        static const int kNlp[] = {4, 8, 12, 16, 24, 32, 48, 64};
+        const int nl = h->dims.n[d - 1];
+        const long outer_rows = sum_n - nl;
+        if (d <= 4 && nl <= 64 && outer_rows * 64 * (long)sizeof(double) <= 64 * 1024 && total <= (1L << 22)) {
+            for (int v : kNlp)
+                if (v >= nl) { h->small_nlp = v; break; }
+            h->small_preferred = total <= kSmallTensorElems && nl <= 48;
+            // 2^e ~ 2 / (node span): exact to apply, keeps the prefix / suffix products of the weights in range
+            std::vector<double> sn((size_t)sum_n);
+            for (int k = 0; k < d; ++k) {
+                const double *nd = nodes_cat + h->dims.off[k];
+                const double span = nd[n_nodes[k] - 1] - nd[0];
+                int e = 0;
+                if (span > 0.0 && std::isfinite(span)) (void)std::frexp(2.0 / span, &e);
+                const double sck = std::ldexp(1.0, e - 1);
+                h->small_scale.s[k] = sck;
+                for (int j = 0; j < n_nodes[k]; ++j) sn[h->dims.off[k] + j] = nd[j] * sck;
+            }
+            CREATE_TRY(hipMalloc((void **)&h->d_snodes, sum_n * sizeof(double)));
+            CREATE_TRY(hipMemcpy(h->d_snodes, sn.data(), sum_n * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
     if (h->mfma_ok) {
         const BaryMfmaPlan &p = h->plan;
         // all-ones rows: the last row of the head part (row codes) and of the tail part (k codes)
@@ -496,8 +539,14 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
 
     // value tensor (derivative spec all-zero) enters the cache at create
     DerivedTensor dt;
-    CREATE_TRY(hipMalloc((void **)&dt.plain, total * sizeof(double)));
-    CREATE_TRY(hipMemcpy(dt.plain, tensor, total * sizeof(double), hipMemcpyHostToDevice));
+    {
+        DevBuf plain;
+        rc = alloc_plain(plain, total);
+        if (rc) { pcx_bary_destroy(h); return rc; }
+        dt.plain = plain.release<double>();
+    }
+    { hipError_t e_ = hipMemcpy(dt.plain, tensor, total * sizeof(double), hipMemcpyHostToDevice);
+      if (e_ != hipSuccess) { (void)hipFree(dt.plain); int c_ = fail(PCX_ERR_HIP, "tensor upload: %s", hipGetErrorString(e_)); pcx_bary_destroy(h); return c_; } }
     rc = bary_pack(h, dt);
     if (rc) { (void)hipFree(dt.plain); pcx_bary_destroy(h); return rc; }
     h->cache[std::vector<int>(d, 0)] = dt;
@@ -574,7 +623,45 @@ extern "C" int pcx_bary_create_from_pcb(int device, const char *path, pcx_bary *
         o1 += n[k];
         o2 += (size_t)n[k] * n[k];
     }
-    return pcx_bary_create(device, (int)d, n.data(), nodes.data(), wts.data(), diff.data(), tensor.data(), out);
+    int rc = pcx_bary_create(device, (int)d, n.data(), nodes.data(), wts.data(), diff.data(), tensor.data(), out);
+    if (rc == PCX_OK) { (*out)->dom_lo = lo; (*out)->dom_hi = hi; }
+    return rc;
+}
+
+// .pcb v1 writer (reference _binary.py:208-283, write side): 12-byte header, d, lower bounds,
+// upper bounds, n_nodes, tensor_values in C order -- all little-endian, no padding.  The tensor
+// is the handle's untransformed device copy, so load -> save reproduces the file byte for byte.
+extern "C" int pcx_bary_save_pcb(pcx_bary *h, const char *path, const double *lo, const double *hi) {
+    if (!h || !path) return fail(PCX_ERR_INVALID, "NULL argument");
+    const int d = h->dims.d;
+    if ((lo == nullptr) != (hi == nullptr)) return fail(PCX_ERR_INVALID, "pass both domain bounds or neither");
+    if (!lo) {
+        if ((int)h->dom_lo.size() != d)
+            return fail(PCX_ERR_INVALID, "the handle does not know its domain (not loaded from a .pcb file): pass lo / hi");
+        lo = h->dom_lo.data();
+        hi = h->dom_hi.data();
+    }
+    for (int k = 0; k < d; ++k)
+        if (!(lo[k] < hi[k])) return fail(PCX_ERR_INVALID, "domain[%d]: lo must be < hi", k);
+    std::vector<double> tensor((size_t)h->total);
+    {
+        HIP_TRY(hipSetDevice(h->device));
+        std::lock_guard<std::mutex> lk(h->mu);
+        const DerivedTensor &base = h->cache[std::vector<int>(d, 0)];
+        HIP_TRY(hipMemcpy(tensor.data(), base.plain, (size_t)h->total * sizeof(double), hipMemcpyDeviceToHost));
+    }
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail(PCX_ERR_INVALID, "cannot open %s for writing", path);
+    const unsigned char head[12] = {'P', 'C', 'B', 0, 1, 0, 1, 0, 0, 0, 0, 0};   // magic, major 1, minor 0, class tag 1
+    const uint32_t du = (uint32_t)d;
+    std::vector<uint32_t> nn(d);
+    for (int k = 0; k < d; ++k) nn[k] = (uint32_t)h->dims.n[k];
+    bool ok = fwrite(head, 1, 12, f) == 12 && fwrite(&du, 4, 1, f) == 1 && fwrite(lo, 8, d, f) == (size_t)d &&
+              fwrite(hi, 8, d, f) == (size_t)d && fwrite(nn.data(), 4, d, f) == (size_t)d &&
+              fwrite(tensor.data(), 8, tensor.size(), f) == tensor.size();
+    ok = (fclose(f) == 0) && ok;
+    if (!ok) return fail(PCX_ERR_INVALID, "short write to %s", path);
+    return PCX_OK;
 }
 
 extern "C" int pcx_bary_shape(pcx_bary *h, int32_t *d_out, int32_t *n_nodes_out) {
@@ -622,9 +709,9 @@ static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **ou
 
     DerivedTensor &base = h->cache[std::vector<int>(d, 0)];
     DevBuf cur, tmp;
-    int rc = cur.alloc(h->total * sizeof(double));
+    int rc = alloc_plain(cur, h->total);
     if (rc) return rc;
-    if ((rc = tmp.alloc(h->total * sizeof(double)))) return rc;
+    if ((rc = alloc_plain(tmp, h->total))) return rc;
     HIP_TRY(hipMemcpyAsync(cur.p, base.plain, h->total * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
     // barycentric.py:982-989: dims descending, order[k] passes each
     for (int k = d - 1; k >= 0; --k) {
@@ -760,6 +847,43 @@ static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts
 }
 
 // Evaluate m specs (dts[0..m)) at N device-resident points; out[p*ostride + ooff + s].
+template <int DOUT, int NLP>
+static int launch_small_t(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N, double *d_out,
+                          long ostride, long ooff, hipStream_t st, const int *perm) {
+    auto kern = k_bary_small<DOUT, NLP>;
+    size_t lds = (size_t)(h->dims.sum_n - h->dims.n[DOUT]) * 64 * sizeof(double);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long blocks = (N + 63) / 64;
+    if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, st, h->dims, h->small_scale, h->d_snodes, h->d_nodes,
+                       h->d_wts, dt.plain, d_pts, d_out, N, ostride, ooff, perm);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+template <int DOUT>
+static int launch_small_d(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N, double *d_out,
+                          long ostride, long ooff, hipStream_t st, const int *perm) {
+    switch (h->small_nlp) {
+#define CASE_NLP(v) case v: return launch_small_t<DOUT, v>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
+    CASE_NLP(4) CASE_NLP(8) CASE_NLP(12) CASE_NLP(16) CASE_NLP(24) CASE_NLP(32) CASE_NLP(48) CASE_NLP(64)
+#undef CASE_NLP
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
+}
+
+static int launch_small(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N, double *d_out,
+                        long ostride, long ooff, hipStream_t st, const int *perm) {
+    switch (h->dims.d) {
+    case 1: return launch_small_d<0>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
+    case 2: return launch_small_d<1>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
+    case 3: return launch_small_d<2>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
+    case 4: return launch_small_d<3>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
+}
+
 // frag_tab is a device table holding the m fragment pointers (MFMA path only).
 // split_scratch (nullable): where split launches of small batches keep their per-chunk sums;
 // perm (nullable): evaluate rows perm[0..N) of d_pts / d_out instead of rows 0..N.
@@ -768,7 +892,15 @@ static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const doub
                        hipStream_t st, Scratch *split_scratch, const int *perm = nullptr) {
     if (N == 0) return PCX_OK;
     int variant = h->variant;
-    if (variant == 0) variant = h->mfma_ok ? 2 : 1;
+    if (variant == 0) variant = (h->small_nlp && (h->small_preferred || !h->mfma_ok)) ? 4 : (h->mfma_ok ? 2 : 1);
+    if (variant == 4) {
+        if (!h->small_nlp) return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
+        for (int s = 0; s < m; ++s) {
+            int rc = launch_small(h, *dts[s], d_pts, N, d_out, ostride, ooff + s, st, perm);
+            if (rc) return rc;
+        }
+        return PCX_OK;
+    }
     if (variant == 3) {
         if (!h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
         return launch_mfma4(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
@@ -959,7 +1091,8 @@ extern "C" int pcx_tensor_contract_axis(int device, int d, const int32_t *n_node
 
 extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
-    if (variant < 0 || variant > 3) return fail(PCX_ERR_INVALID, "variant %d outside [0, 3]", variant);
+    if (variant < 0 || variant > 4) return fail(PCX_ERR_INVALID, "variant %d outside [0, 4]", variant);
+    if (variant == 4 && !h->small_nlp) return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
     if (variant == 2 && !h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
     if (variant == 3 && !h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
     std::lock_guard<std::mutex> lk(h->mu);
@@ -969,7 +1102,7 @@ extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
 
 extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
     if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
-    info[0] = h->mfma_ok ? 2 : 1;
+    info[0] = (h->small_nlp && (h->small_preferred || !h->mfma_ok)) ? 4 : (h->mfma_ok ? 2 : 1);
     info[1] = h->mfma_ok ? h->plan.MT : 0;
     info[2] = h->mfma_ok ? h->plan.KS : 0;
     info[3] = h->mfma_ok ? (int32_t)mfma_lds_bytes(h->dims, h->nt) : (256 / h->lpp) * h->dims.sum_n * 8;
@@ -1700,18 +1833,77 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
         for (int i = 0; i < m; ++i) fro2 += hnorm[i];
         const double eps64 = 8.0 * 2.220446049250313e-16;   // rows below 8 eps ||C||_F: noise
         const double floor2 = eps64 * eps64 * fro2;
-        if (m > 1) {
-            for (int sweep = 0; sweep < 60; ++sweep) {
-                HIP_TRY(hipMemsetAsync(drot.p, 0, sizeof(int), 0));
-                for (int step = 0; step < mp - 1; ++step)
-                    hipLaunchKernelGGL(k_rowjacobi_step, dim3(mp / 2), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, m, N,
-                                       U.as<double>(), step, drot.as<int>(), floor2);
+        // pairs of rows that are both under tol times the largest row norm (<= sigma_max) are not rotated
+        // against each other: see k_rowjacobi_step
+        double row_max2 = 0.0;
+        for (int i = 0; i < m; ++i) row_max2 = std::max(row_max2, hnorm[i]);
+        const double sig2 = tol * tol * row_max2;
+        const double rot_tol = std::max(1e-15, 2.0 * 2.220446049250313e-16 * std::sqrt((double)N));
+        size_t lds_rows = (size_t)m * N * sizeof(double);
+        if (m > 1 && lds_rows <= 144 * 1024) {
+            // small unfolding: the whole iteration in one workgroup, rows (and U when it fits) in LDS, one launch
+            const int u_in_lds = (lds_rows + (size_t)m * m * sizeof(double) <= 156 * 1024) ? 1 : 0;
+            if (u_in_lds) lds_rows += (size_t)m * m * sizeof(double);
+            if (lds_rows > 48 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)k_rowjacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rows));
+            HIP_TRY(hipMemsetAsync(drot.p, 0, sizeof(int), 0));
+            hipLaunchKernelGGL(k_rowjacobi_lds, dim3(1), dim3(TTSVD_LDS_THREADS), lds_rows, 0, cur.as<double>(), m, (int)N,
+                               U.as<double>(), floor2, rot_tol, sig2, 60, drot.as<int>(), u_in_lds);
+            HIP_TRY(hipGetLastError());
+            int sw = 0;
+            HIP_TRY(hipMemcpy(&sw, drot.p, sizeof(int), hipMemcpyDeviceToHost));
+            sweeps_total += sw;
+        } else if (m > 1) {
+            // large unfolding: one launch per tournament step, a sweep's (mp - 1) launches recorded once
+            // in a hipGraph and replayed per sweep (the host could not issue ~100 tiny launches per
+            // sweep at the rate the device finishes them: ~4 us each against ~1.5 us per boundary)
+            // Gram preconditioner (ttsvd_kernels.h): rotations found on the m x m matrix C C^T in LDS make the
+            // rows nearly orthogonal before the accurate row iteration starts
+            const size_t lds_sym = ((size_t)2 * m * m + 2 * ((m + 1) / 2 + 1)) * sizeof(double) + (size_t)(m + 2) * sizeof(int);
+            if (N > 2L * m && lds_sym <= 156 * 1024) {
+                DevBuf G;
+                if ((rc = G.alloc((size_t)m * m * sizeof(double)))) return rc;
+                hipLaunchKernelGGL(k_gram_rows, dim3(m, m), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, m, N, G.as<double>());
+                if (lds_sym > 48 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void *)k_symjacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sym));
+                hipLaunchKernelGGL(k_symjacobi_lds, dim3(1), dim3(TTSVD_LDS_THREADS), lds_sym, 0, G.as<double>(), m, U.as<double>(),
+                                   std::max(floor2, 1e-13 * fro2), 1e-9, 30);
+                hipLaunchKernelGGL(k_apply_vt, dim3((unsigned)((N + 255) / 256), m), dim3(256), 0, 0, cur.as<double>(), N, m, N,
+                                   U.as<double>(), nxt.as<double>());
                 HIP_TRY(hipGetLastError());
+                HIP_TRY(hipDeviceSynchronize());
+                std::swap(cur.p, nxt.p);
+            }
+            hipStream_t cs = nullptr;
+            HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+            hipGraph_t graph = nullptr;
+            hipGraphExec_t exec = nullptr;
+            auto cleanup = [&]() {
+                if (exec) (void)hipGraphExecDestroy(exec);
+                if (graph) (void)hipGraphDestroy(graph);
+                (void)hipStreamDestroy(cs);
+            };
+            HIP_TRY(hipDeviceSynchronize());       // the identity / norm kernels above ran on the NULL stream
+            hipError_t ge = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+            if (ge == hipSuccess) {
+                for (int step = 0; step < mp - 1; ++step)
+                    hipLaunchKernelGGL(k_rowjacobi_step, dim3(mp / 2), dim3(TTSVD_THREADS), 0, cs, cur.as<double>(), N, m, N,
+                                       U.as<double>(), step, drot.as<int>(), floor2, rot_tol, sig2);
+                ge = hipStreamEndCapture(cs, &graph);
+            }
+            if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            if (ge != hipSuccess) { cleanup(); return fail(PCX_ERR_HIP, "TT-SVD sweep graph: %s", hipGetErrorString(ge)); }
+            for (int sweep = 0; sweep < 60; ++sweep) {
                 int rotated = 0;
-                HIP_TRY(hipMemcpy(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost));
+                hipError_t e = hipMemsetAsync(drot.p, 0, sizeof(int), cs);
+                if (e == hipSuccess) e = hipGraphLaunch(exec, cs);
+                if (e == hipSuccess) e = hipMemcpyAsync(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost, cs);
+                if (e == hipSuccess) e = hipStreamSynchronize(cs);
+                if (e != hipSuccess) { cleanup(); return fail(PCX_ERR_HIP, "TT-SVD sweep: %s", hipGetErrorString(e)); }
                 ++sweeps_total;
                 if (rotated == 0) break;
             }
+            cleanup();
         }
         hipLaunchKernelGGL(k_row_sqnorms, dim3(m), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, N, nrm.as<double>());
         HIP_TRY(hipGetLastError());

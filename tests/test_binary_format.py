@@ -133,6 +133,45 @@ def test_models_loaded_from_pcb_evaluate_like_the_reference(tmp_path):
     assert lib.pcx_bary_create_from_pcb(0, b"/nonexistent/x.pcb", ctypes.byref(h)) == _lib.PCX_ERR_INVALID
 
 
+@pytest.mark.gpu
+def test_c_side_pcb_writer_round_trips_the_reference_fixtures_byte_for_byte(tmp_path):
+    """pcx_bary_save_pcb (the write side of reference _binary.py:208-283 in the C ABI): file ->
+    device handle -> file reproduces the reference's own fixtures exactly; a handle built from
+    arrays writes the same bytes as the Python writer when given the domain."""
+    lib = _lib.load()
+    for name in ("approx_5d_bs.pcb", "approx_2d_simple.pcb"):
+        src = os.path.join(GOLDEN, name)
+        h = ctypes.c_void_p()
+        _lib.check(lib.pcx_bary_create_from_pcb(0, src.encode(), ctypes.byref(h)), lib)
+        try:
+            dst = tmp_path / ("copy_" + name)
+            _lib.check(lib.pcx_bary_save_pcb(h, str(dst).encode(), None, None), lib)
+            assert dst.read_bytes() == open(src, "rb").read()
+            # a derivative evaluation in between must not disturb what is written (the cache holds T' beside T)
+            d = ctypes.c_int32()
+            _lib.check(lib.pcx_bary_shape(h, ctypes.byref(d), None), lib)
+            pts = _lib.f64(np.zeros((3, d.value)))
+            out = np.empty(3)
+            spec = _lib.i32([1] + [0] * (d.value - 1))
+            _lib.check(lib.pcx_bary_eval_batch(h, _lib.p_f64(pts), 3, _lib.p_i32(spec), _lib.p_f64(out)), lib)
+            _lib.check(lib.pcx_bary_save_pcb(h, str(dst).encode(), None, None), lib)
+            assert dst.read_bytes() == open(src, "rb").read()
+        finally:
+            lib.pcx_bary_destroy(h)
+    c = _xy()
+    m = c._model()
+    lo, hi = _lib.f64([-1.0, -1.0]), _lib.f64([1.0, 1.0])
+    out = tmp_path / "xy.pcb"
+    _lib.check(lib.pcx_bary_save_pcb(m.handle, str(out).encode(), _lib.p_f64(lo), _lib.p_f64(hi)), lib)
+    assert out.read_bytes() == _bytes(c)
+    assert ChebyshevApproximation.load(str(out)).n_nodes == [3, 3]
+    # argument errors
+    assert lib.pcx_bary_save_pcb(m.handle, str(out).encode(), None, None) == _lib.PCX_ERR_INVALID      # domain unknown
+    assert b"domain" in lib.pcx_last_error()
+    assert lib.pcx_bary_save_pcb(m.handle, str(out).encode(), _lib.p_f64(hi), _lib.p_f64(lo)) == _lib.PCX_ERR_INVALID
+    assert lib.pcx_bary_save_pcb(m.handle, b"/nonexistent-dir/x.pcb", _lib.p_f64(lo), _lib.p_f64(hi)) == _lib.PCX_ERR_INVALID
+
+
 # ------------------------------------------------------------------ splines (class tag 2)
 def test_spline_pcb_round_trip_is_byte_exact_with_the_reference(tmp_path):
     """Read the file the reference wrote (tests/golden/spline_2d_ref.pcb), write it back:

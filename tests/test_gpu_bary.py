@@ -191,17 +191,22 @@ def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     if all(v > 2 for v in shape):
         specs.append([1] + [0] * (d - 1))
         specs.append([0] * (d - 1) + [2])
-    for s in specs:
-        ref = oracle_mod.bary_eval_batch(om, pts, s)
-        assert_parity(c.vectorized_eval_batch(pts, s), ref, 1e-12, f"{shape} {s}", spec_point_tol(s),
-                      floor=np.max(np.abs(T)))
     info = _lib.i32(np.zeros(6))
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
+    mfma_planned = m.lib.pcx_bary_set_kernel(m.handle, 2) == 0       # the MFMA plan exists for this shape
+    for variant in ((0, 2) if mfma_planned and info[0] != 2 else (0,)):
+        _set_kernel(c, variant)
+        for s in specs:
+            ref = oracle_mod.bary_eval_batch(om, pts, s)
+            assert_parity(c.vectorized_eval_batch(pts, s), ref, 1e-12, f"{shape} {s} v{variant}", spec_point_tol(s),
+                          floor=np.max(np.abs(T)))
     if shape in ((2, 300), (250, 250)):
-        assert info[0] == 1, "expected the rows kernel for this shape"
-    elif d >= 8 or shape in ((2, 200), (14, 13, 15), (16,) * 4, (100, 90, 70), (200, 80)):
+        assert info[0] == 1 and not mfma_planned, "expected the rows kernel for this shape"
+    elif d >= 8 or shape in ((2, 200), (16,) * 4, (100, 90, 70), (200, 80)):
         assert info[0] == 2, "expected the MFMA kernel for this shape"
+    elif shape == (14, 13, 15):
+        assert info[0] == 4 and mfma_planned      # 2730 elements: lane-per-point by default, MFMA plan (K = 195) also run
 
 
 def test_both_mfma_forms_are_bit_identical(bs5d):
@@ -670,3 +675,42 @@ def test_derivative_order_rules_of_the_reference_on_the_device(bs5d, oracle_mod)
     c3 = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES, max_derivative_order=3)
     did = c3.get_derivative_id(third)
     assert np.array_equal(c3.vectorized_eval_batch(pts, derivative_id=did), c.vectorized_eval_batch(pts, third))
+
+
+@pytest.mark.parametrize("shape", [(12, 12), (1,), (64,), (5,), (9, 7, 6), (2, 3, 4, 5), (64, 64), (33, 2), (1, 1, 1, 13),
+                                   (20, 20, 20)])
+def test_lane_per_point_kernel_for_small_tensors(oracle_mod, shape):
+    """k_bary_small (variant 4; what auto picks up to 4096 elements, last dimension <= 48): every padded last-dimension
+    width, d = 1..4, derivative specs, exact-node rows, ragged batches -- against the oracle, and
+    bit-compatible row by row with whatever batch the point sits in."""
+    rng = np.random.default_rng(sum(shape) + len(shape))
+    d = len(shape)
+    T = rng.standard_normal(shape)
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-5, 5, d), rng.uniform(0.5, 5, d))]
+    c = ChebyshevApproximation.from_values(T, d, dom, list(shape))
+    om = _oracle_model(oracle_mod, c)
+    _set_kernel(c, 4)
+    info = _lib.i32(np.zeros(6))
+    m = c._model()
+    m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
+    assert info[0] == (4 if (T.size <= 4096 and shape[-1] <= 48) else 2)
+    specs = [[0] * d]
+    if all(v > 2 for v in shape):
+        specs += [[1] + [0] * (d - 1), [0] * (d - 1) + [2]]
+    for npts in (1, 63, 64, 65, 1000):
+        pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+        pts[0] = [c.nodes[k][-1] for k in range(d)]                 # a grid point
+        if npts > 2:
+            pts[2, d - 1] = c.nodes[d - 1][0]                         # exact node in the register dimension only
+        for s in specs:
+            ref = oracle_mod.bary_eval_batch(om, pts, s)
+            got = c.vectorized_eval_batch(pts, s)
+            assert_parity(got, ref, 1e-12, f"small {shape} {s} N={npts}", spec_point_tol(s), floor=np.max(np.abs(T)))
+            if s == specs[0]:
+                assert got[0] == T[tuple(v - 1 for v in shape)]
+    pts = np.column_stack([rng.uniform(lo, hi, 300) for lo, hi in dom])
+    whole = c.vectorized_eval_batch(pts, specs[0])
+    assert np.array_equal(whole[100:133], c.vectorized_eval_batch(pts[100:133], specs[0]))
+    multi = c.vectorized_eval_multi_batch(pts, specs)
+    for j, s in enumerate(specs):
+        assert np.array_equal(multi[:, j], c.vectorized_eval_batch(pts, s))

@@ -235,3 +235,63 @@ def test_tt_svd_restatement(oracle_mod):
         assert [1] + [c.shape[2] for c in vc] == list(g[f"bs_{tag}_ranks"])
         y = o.tt_eval_batch([o.value_to_coeff_core(c) for c in vc], F.BS5_DOMAIN, g["bs_points"])
         assert_parity(y, g[f"bs_{tag}_eval"], 1e-10, f"TT-SVD BS {tag}")
+
+
+def test_c_restatement_is_clean_under_address_sanitizer(tmp_path):
+    """run the CPU restatement under -fsanitize=address (the GPU pool has no
+    sanitizer; the kernels mirror these loops).  A child interpreter preloads libasan, loads
+    oracle/libpcx_oracle_asan.so and drives every C entry point on the golden inputs, including
+    the edge shapes (n = 1, exact nodes, ragged batches); any out-of-bounds access aborts it."""
+    import shutil
+    import subprocess
+    import sys
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    libasan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(libasan) or not os.path.exists(libasan):
+        pytest.skip("libasan not installed")
+    odir = os.path.join(ROOT, "oracle")
+    res = subprocess.run(["make", "-C", odir, "libpcx_oracle_asan.so"], capture_output=True, text=True)
+    assert res.returncode == 0, res.stdout + res.stderr
+    script = tmp_path / "drive.py"
+    script.write_text(f"""
+import os, sys
+import numpy as np
+sys.path.insert(0, {ROOT!r}); sys.path.insert(0, {GOLDEN!r})
+import oracle
+import functions as F
+g = np.load(os.path.join({GOLDEN!r}, "g2_bs5d.npz"))
+m = oracle.BaryModel.from_domain(F.BS5_DOMAIN, F.BS5_NODES, g["tensor"])
+oracle.set_num_threads(4)
+for s, ref in zip(g["specs"], g["out"]):
+    y = oracle.bary_eval_batch(m, g["points"][:600], list(s))
+    assert np.max(np.abs(y - ref[:600])) <= 1e-12 * np.max(np.abs(ref))
+oracle.bary_eval_multi(m, g["points"][7], [list(s) for s in g["specs"]])
+rng = np.random.default_rng(0)
+for shape in [(1,), (1, 1), (2, 1, 3), (7,), (3, 4, 5, 2)]:
+    T = rng.standard_normal(shape)
+    mm = oracle.BaryModel.from_domain([[0.0, 1.0]] * len(shape), list(shape), T)
+    for npts in (0, 1, 3, 65):
+        pts = rng.uniform(0, 1, (npts, len(shape)))
+        if npts:
+            pts[0] = [mm.nodes_cat[0]] * len(shape)
+        oracle.bary_eval_batch(mm, pts, [0] * len(shape))
+        if min(shape) > 2:
+            oracle.bary_eval_batch(mm, pts, [2] + [0] * (len(shape) - 1))
+g4 = np.load(os.path.join({GOLDEN!r}, "g4_tt_bs5d.npz"))
+cores = [g4[f"r8_core{{k}}"] for k in range(5)]
+y = oracle.tt_eval_batch(cores, F.BS5_DOMAIN, g4["points"][:500])
+assert np.max(np.abs(y - g4["r8_eval"][:500])) <= 1e-12 * np.max(np.abs(g4["r8_eval"]))
+oracle.tt_eval_batch(cores, F.BS5_DOMAIN, g4["points"][:0])
+oracle.tt_eval_batch(cores, F.BS5_DOMAIN, g4["points"][:33], dim_order=[4, 3, 2, 1, 0])
+oracle.tt_eval_multi(cores, F.BS5_DOMAIN, list(g4["points"][3]), [[0] * 5, [1, 0, 0, 0, 0], [2, 0, 0, 0, 0], [1, 1, 0, 0, 0]])
+vc = [rng.standard_normal((1, 4, 3)), rng.standard_normal((3, 5, 2)), rng.standard_normal((2, 3, 1))]
+oracle.tt_eval_grid(vc, [3, 4, 2])
+oracle.value_to_coeff_core(vc[1])
+print("asan-clean")
+""")
+    env = dict(os.environ, LD_PRELOAD=libasan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=1",
+               PCX_ORACLE_LIBRARY=os.path.join(odir, "libpcx_oracle_asan.so"), OMP_NUM_THREADS="4")
+    res = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0 and "asan-clean" in res.stdout, res.stdout[-1500:] + res.stderr[-3000:]
+    assert "AddressSanitizer" not in res.stderr

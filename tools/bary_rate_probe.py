@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Device-resident vectorized_eval_batch throughput over tensor shapes: which shapes get the
-MFMA kernel (and with which plan), which fall back to the row-parallel VALU kernel.
+"""Device-resident vectorized_eval_batch throughput over tensor shapes: which kernel auto picks
+(lane-per-point for small tensors, MFMA and its plan, or the row-parallel VALU kernel), next to
+each kernel forced.  frac = the reference's nested-reduction flop count / 78.6 TFLOP/s (FP64);
+hbm = 8 (d + 1) bytes per point / 8 TB/s -- the roofline that binds tiny tensors.
 
     python tools/bary_rate_probe.py [--points 1000000]
 """
@@ -27,7 +29,7 @@ def rate(shape, npts, variant=0):
     info = (ctypes.c_int32 * 6)()
     _lib.check(lib.pcx_bary_kernel_info(m.handle, info), lib)
     if variant and lib.pcx_bary_set_kernel(m.handle, variant) != 0:
-        return None, list(info)
+        return (float("nan"),) * 3, list(info)
     pts = rng.uniform(-1, 1, (npts, d))
     dev = _lib.default_device()
     d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
@@ -52,23 +54,29 @@ def rate(shape, npts, variant=0):
     for n in reversed(shape):          # the reference's nested reduction: prod, prod/n_last, ...
         fma += size
         size //= n
-    return (npts / dt, 2.0 * fma * npts / dt / 78.6e12), list(info)
+    return (npts / dt, 2.0 * fma * npts / dt / 78.6e12, 8.0 * (d + 1) * npts / dt / 8e12), list(info)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=1_000_000)
     a = ap.parse_args()
-    print(f"{'shape':<28} {'kernel':<22} {'pts/s':>11} {'frac':>6}   {'rows pts/s':>11} {'frac':>6}")
-    shapes = [(11,) * 5, (7,) * 5, (5,) * 6, (15,) * 4, (21,) * 3, (33, 33), (64, 64), (200,), (12, 12),
-              (9, 11, 13, 7), (4,) * 8, (3,) * 10, (6, 11, 11, 11, 11), (11, 11, 11, 11, 6), (16,) * 4, (20,) * 3]
+    print(f"{'shape':<16} {'auto kernel':<26} {'pts/s':>11} {'fp64':>6} {'hbm':>6}   {'lane/pt pts/s':>13} {'fp64':>6}   "
+          f"{'mfma pts/s':>11} {'fp64':>6}   {'rows pts/s':>11} {'fp64':>6}")
+    shapes = [(11,) * 5, (7,) * 5, (5,) * 6, (15,) * 4, (21,) * 3, (33, 33), (64, 64), (200,), (12, 12), (9, 7, 6),
+              (6, 6, 6, 6), (8, 8, 8), (16, 16, 16), (11, 11, 11), (9, 11, 13, 7), (4,) * 8, (3,) * 10, (6, 11, 11, 11, 11),
+              (11, 11, 11, 11, 6), (16,) * 4, (20,) * 3, (65,) * 3, (64,) * 4]
     for shape in shapes:
-        npts = a.points if np.prod(shape) > 2000 else 4 * a.points
+        size = int(np.prod(shape))
+        npts = 4 * a.points if size <= 2000 else (a.points if size < 4_000_000 else a.points // 8)
         auto, info = rate(shape, npts)
-        rows, _ = rate(shape, npts, variant=1)
-        kern = f"mfma MT={info[1]} KS={info[2]} split={info[5]}" if info[0] == 2 else "rows"
+        small, _ = rate(shape, npts, variant=4)
+        mfma, _ = rate(shape, npts, variant=2)
+        rows, _ = rate(shape, npts // 4 if size > 100_000 else npts, variant=1)
+        kern = {4: "lane-per-point", 1: "rows"}.get(info[0], f"mfma MT={info[1]} KS={info[2]} split={info[5]}")
         name = "x".join(str(n) for n in shape) if len(set(shape)) > 1 else f"{shape[0]}^{len(shape)}"
-        print(f"{name:<28} {kern:<22} {auto[0]:11.4e} {auto[1]:6.3f}   {rows[0]:11.4e} {rows[1]:6.3f}")
+        print(f"{name:<16} {kern:<26} {auto[0]:11.4e} {auto[1]:6.3f} {auto[2]:6.3f}   {small[0]:13.4e} {small[1]:6.3f}   "
+              f"{mfma[0]:11.4e} {mfma[1]:6.3f}   {rows[0]:11.4e} {rows[1]:6.3f}")
 
 
 if __name__ == "__main__":
