@@ -205,7 +205,8 @@ class _DeviceModel:
         self.lib = lib
         self.handle = handle
         self.device = device
-        self.tensor_id = id(approx.tensor_values)
+        # the array object itself, not its id(): an id can be reused once the old array is collected
+        self.tensor_ref = approx.tensor_values
 
     def __del__(self):
         try:
@@ -422,9 +423,12 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         self._device_model = None
 
     def _model(self) -> _DeviceModel:
+        """The device copy for ``_device_index`` (default device when unset); rebuilt when
+        ``tensor_values`` was replaced or the copy lives on another device."""
         m = self._device_model
-        if m is None or m.tensor_id != id(self.tensor_values):
-            self.to_device(self._device_index)
+        want = _lib.default_device() if self._device_index is None else int(self._device_index)
+        if m is None or m.tensor_ref is not self.tensor_values or m.device != want:
+            self.to_device(want)
             m = self._device_model
         return m
 
