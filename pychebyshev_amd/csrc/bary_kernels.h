@@ -695,8 +695,11 @@ struct BarySmallScale {
 template <int DOUT, int NLP>
 __global__ void __launch_bounds__(64)
 k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, const double *__restrict__ nodes,
-             const double *__restrict__ wts, const double *__restrict__ T, const double *__restrict__ pts,
-             double *__restrict__ out, long N, long ostride, long ooff, const int *__restrict__ perm) {
+             const double *__restrict__ wts, const double *__restrict__ T, const double *const *__restrict__ T_tab,
+             int m, const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
+             const int *__restrict__ perm) {
+    // m derivative specs in one launch (T_tab: device table of m tensors; NULL: the single tensor T):
+    // the weights of a point are formed once and every tensor is contracted with them.
     extern __shared__ double lds[];
     const int lane = threadIdx.x;
     const long pidx = (long)blockIdx.x * 64 + lane;
@@ -716,8 +719,15 @@ k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes
         bary_weights_reg<NLP>(x, sc.s[DOUT], snodes + dims.off[DOUT], wts + dims.off[DOUT], dims.n[DOUT], bl);
     }
     // the table is wave-private (one wave per workgroup): no barrier
-    const double y = bary_small_nest<0, DOUT, NLP>(dims, T, bw_lane, bl);
-    if (valid) out[row * ostride + ooff] = y;
+    if (T_tab == nullptr) {
+        const double y = bary_small_nest<0, DOUT, NLP>(dims, T, bw_lane, bl);
+        if (valid) out[row * ostride + ooff] = y;
+    } else {
+        for (int z = 0; z < m; ++z) {
+            const double y = bary_small_nest<0, DOUT, NLP>(dims, T_tab[z], bw_lane, bl);
+            if (valid) out[row * ostride + ooff + z] = y;
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------

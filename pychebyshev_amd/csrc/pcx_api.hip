@@ -847,9 +847,10 @@ static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts
 }
 
 // Evaluate m specs (dts[0..m)) at N device-resident points; out[p*ostride + ooff + s].
+// T_tab (device table of m plain tensors) or, when NULL, the single tensor dt
 template <int DOUT, int NLP>
-static int launch_small_t(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N, double *d_out,
-                          long ostride, long ooff, hipStream_t st, const int *perm) {
+static int launch_small_t(pcx_bary *h, const DerivedTensor &dt, const double *const *T_tab, int m, const double *d_pts,
+                          long N, double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
     auto kern = k_bary_small<DOUT, NLP>;
     size_t lds = (size_t)(h->dims.sum_n - h->dims.n[DOUT]) * 64 * sizeof(double);
     if (lds > 64 * 1024)
@@ -857,49 +858,52 @@ static int launch_small_t(pcx_bary *h, const DerivedTensor &dt, const double *d_
     long blocks = (N + 63) / 64;
     if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, st, h->dims, h->small_scale, h->d_snodes, h->d_nodes,
-                       h->d_wts, dt.plain, d_pts, d_out, N, ostride, ooff, perm);
+                       h->d_wts, dt.plain, T_tab, m, d_pts, d_out, N, ostride, ooff, perm);
     HIP_TRY(hipGetLastError());
     return PCX_OK;
 }
 
 template <int DOUT>
-static int launch_small_d(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N, double *d_out,
-                          long ostride, long ooff, hipStream_t st, const int *perm) {
+static int launch_small_d(pcx_bary *h, const DerivedTensor &dt, const double *const *T_tab, int m, const double *d_pts,
+                          long N, double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
     switch (h->small_nlp) {
-#define CASE_NLP(v) case v: return launch_small_t<DOUT, v>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
+#define CASE_NLP(v) case v: return launch_small_t<DOUT, v>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
     CASE_NLP(4) CASE_NLP(8) CASE_NLP(12) CASE_NLP(16) CASE_NLP(24) CASE_NLP(32) CASE_NLP(48) CASE_NLP(64)
 #undef CASE_NLP
     }
     return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
 }
 
-static int launch_small(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N, double *d_out,
-                        long ostride, long ooff, hipStream_t st, const int *perm) {
+static int launch_small(pcx_bary *h, const DerivedTensor &dt, const double *const *T_tab, int m, const double *d_pts,
+                        long N, double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
     switch (h->dims.d) {
-    case 1: return launch_small_d<0>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
-    case 2: return launch_small_d<1>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
-    case 3: return launch_small_d<2>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
-    case 4: return launch_small_d<3>(h, dt, d_pts, N, d_out, ostride, ooff, st, perm);
+    case 1: return launch_small_d<0>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+    case 2: return launch_small_d<1>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+    case 3: return launch_small_d<2>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+    case 4: return launch_small_d<3>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
     }
     return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
 }
 
-// frag_tab is a device table holding the m fragment pointers (MFMA path only).
+// the kernel a launch will take: 1 rows, 2 MFMA 16x16x4, 3 MFMA 4x4x4, 4 lane-per-point
+static int bary_effective_variant(const pcx_bary *h) {
+    if (h->variant != 0) return h->variant;
+    return (h->small_nlp && (h->small_preferred || !h->mfma_ok)) ? 4 : (h->mfma_ok ? 2 : 1);
+}
+
+// frag_tab is a device table holding the m tensor pointers of a multi-spec launch: fragment images for
+// the MFMA kernels, plain tensors for the lane-per-point kernel (see bary_spec_table); for m = 1 the MFMA
+// kernels read dts[0]->slot and the lane-per-point kernel takes dts[0]->plain directly.
 // split_scratch (nullable): where split launches of small batches keep their per-chunk sums;
 // perm (nullable): evaluate rows perm[0..N) of d_pts / d_out instead of rows 0..N.
 static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const double *const *frag_tab,
                        const double *d_pts, long N, double *d_out, long ostride, long ooff,
                        hipStream_t st, Scratch *split_scratch, const int *perm = nullptr) {
     if (N == 0) return PCX_OK;
-    int variant = h->variant;
-    if (variant == 0) variant = (h->small_nlp && (h->small_preferred || !h->mfma_ok)) ? 4 : (h->mfma_ok ? 2 : 1);
+    const int variant = bary_effective_variant(h);
     if (variant == 4) {
         if (!h->small_nlp) return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
-        for (int s = 0; s < m; ++s) {
-            int rc = launch_small(h, *dts[s], d_pts, N, d_out, ostride, ooff + s, st, perm);
-            if (rc) return rc;
-        }
-        return PCX_OK;
+        return launch_small(h, *dts[0], m > 1 ? frag_tab : nullptr, m, d_pts, N, d_out, ostride, ooff, st, perm);
     }
     if (variant == 3) {
         if (!h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
@@ -970,9 +974,10 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         if (rc) return rc;
     }
     const double *const *frag_tab = dts[0]->slot;
-    if (m > 1 && h->mfma_ok) {
+    const int eff = bary_effective_variant(h);
+    if (m > 1 && (eff == 4 || h->mfma_ok)) {
         std::vector<double *> tab(m);
-        for (int s = 0; s < m; ++s) tab[s] = dts[s]->frag;
+        for (int s = 0; s < m; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
         if (tab != h->tab_host) {   // every earlier launch on this handle has been synchronised
             HIP_TRY(hipMemcpy(h->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
             h->tab_host = tab;
@@ -1102,7 +1107,7 @@ extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
 
 extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
     if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
-    info[0] = (h->small_nlp && (h->small_preferred || !h->mfma_ok)) ? 4 : (h->mfma_ok ? 2 : 1);
+    { const int keep = h->variant; h->variant = 0; info[0] = bary_effective_variant(h); h->variant = keep; }
     info[1] = h->mfma_ok ? h->plan.MT : 0;
     info[2] = h->mfma_ok ? h->plan.KS : 0;
     info[3] = h->mfma_ok ? (int32_t)mfma_lds_bytes(h->dims, h->nt) : (256 / h->lpp) * h->dims.sum_n * 8;
@@ -1255,9 +1260,10 @@ static int spline_eval_host(pcx_spline *h, const double *pts, int64_t N, const i
                 if (rc) return rc;
             }
             const double *const *frag_tab = dts[0]->slot;
-            if (m > 1 && pc->mfma_ok) {
+            const int eff = bary_effective_variant(pc);
+            if (m > 1 && (eff == 4 || pc->mfma_ok)) {
                 std::vector<double *> tab(m);
-                for (int s = 0; s < m; ++s) tab[s] = dts[s]->frag;
+                for (int s = 0; s < m; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
                 if (tab != pc->tab_host) {
                     HIP_TRY(hipStreamSynchronize(h->stream));   // earlier launches may still read d_tab
                     HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
