@@ -210,6 +210,12 @@ struct DevBuf {
     template <typename T> T *release() { T *q = (T *)p; p = nullptr; return q; }
 };
 
+// typed view of memory somebody else owns (a Scratch)
+struct DevView {
+    void *p;
+    template <typename T> T *as() { return (T *)p; }
+};
+
 // "Plain" (C-order) tensors carry PCX_PLAIN_PAD zeroed doubles behind their end: k_bary_small reads a
 // row with a fixed-width run of scalar loads that may reach past the last row.
 static int alloc_plain(DevBuf &b, long total) {
@@ -1808,7 +1814,9 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
     }
     int rc = use_device(device);
     if (rc) return rc;
-    DevBuf cur, nxt, dU, dnorm, drot, drows;
+    DevBuf cur, nxt, drot;
+    Scratch sU, snrm, srows, sG;          // grow-only work buffers shared by the unfoldings
+    struct Release { Scratch &a, &b, &c, &d; ~Release() { a.release(); b.release(); c.release(); d.release(); } } rel{sU, snrm, srows, sG};
     if ((rc = cur.alloc((size_t)total * sizeof(double)))) return rc;
     if ((rc = nxt.alloc((size_t)total * sizeof(double)))) return rc;
     if ((rc = drot.alloc(sizeof(int)))) return rc;
@@ -1825,10 +1833,10 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
         if (m_l > 8192) return fail(PCX_ERR_UNSUPPORTED, "TT-SVD unfolding with %ld rows (> 8192)", m_l);
         const int m = (int)m_l;
         const long N = elems / m;
-        DevBuf U, nrm, rows;
-        if ((rc = U.alloc((size_t)m * m * sizeof(double)))) return rc;
-        if ((rc = nrm.alloc((size_t)m * sizeof(double)))) return rc;
-        if ((rc = rows.alloc((size_t)m * sizeof(int)))) return rc;
+        if ((rc = sU.reserve((size_t)m * m * sizeof(double)))) return rc;
+        if ((rc = snrm.reserve((size_t)m * sizeof(double)))) return rc;
+        if ((rc = srows.reserve((size_t)m * sizeof(int)))) return rc;
+        DevView U{sU.ptr}, nrm{snrm.ptr}, rows{srows.ptr};
         hipLaunchKernelGGL(k_set_identity, dim3((unsigned)(((long)m * m + 255) / 256)), dim3(256), 0, 0, U.as<double>(), m);
         const int mp = (m + 1) & ~1;
         // squared norm of the largest row bounds sigma_max^2 from below (and sigma_max^2 <= m times it)
@@ -1867,8 +1875,8 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
             // rows nearly orthogonal before the accurate row iteration starts
             const size_t lds_sym = ((size_t)2 * m * m + 2 * ((m + 1) / 2 + 1)) * sizeof(double) + (size_t)(m + 2) * sizeof(int);
             if (N > 2L * m && lds_sym <= 156 * 1024) {
-                DevBuf G;
-                if ((rc = G.alloc((size_t)m * m * sizeof(double)))) return rc;
+                if ((rc = sG.reserve((size_t)m * m * sizeof(double)))) return rc;
+                DevView G{sG.ptr};
                 hipLaunchKernelGGL(k_gram_rows, dim3(m, m), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, m, N, G.as<double>());
                 if (lds_sym > 48 * 1024)
                     HIP_TRY(hipFuncSetAttribute((const void *)k_symjacobi_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_sym));
@@ -1880,6 +1888,20 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
                 HIP_TRY(hipDeviceSynchronize());
                 std::swap(cur.p, nxt.p);
             }
+            if (mp - 1 <= 16) {
+                // a short tournament (the 11-row first unfolding): plain launches, no graph to build
+                for (int sweep = 0; sweep < 60; ++sweep) {
+                    HIP_TRY(hipMemsetAsync(drot.p, 0, sizeof(int), 0));
+                    for (int step = 0; step < mp - 1; ++step)
+                        hipLaunchKernelGGL(k_rowjacobi_step, dim3(mp / 2), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, m, N,
+                                           U.as<double>(), step, drot.as<int>(), floor2, rot_tol, sig2);
+                    HIP_TRY(hipGetLastError());
+                    int rotated = 0;
+                    HIP_TRY(hipMemcpy(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost));
+                    ++sweeps_total;
+                    if (rotated == 0) break;
+                }
+            } else {
             hipStream_t cs = nullptr;
             HIP_TRY(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
             hipGraph_t graph = nullptr;
@@ -1910,6 +1932,7 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
                 if (rotated == 0) break;
             }
             cleanup();
+            }
         }
         hipLaunchKernelGGL(k_row_sqnorms, dim3(m), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, N, nrm.as<double>());
         HIP_TRY(hipGetLastError());
