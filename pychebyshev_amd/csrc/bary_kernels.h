@@ -603,7 +603,10 @@ k_bary_rows(BaryDims dims, int LPP, const double *__restrict__ nodes,
 // beyond n_last; the row read runs up to NLP - n_last doubles into the next row, which is
 // multiplied by those zeros: tensors carry PCX_PLAIN_PAD zeroed doubles behind their end), the
 // outer dimensions' weights in a per-wave LDS table [row][lane], read once per inner row.
-// One FMA per tensor element and one per inner result: the algorithmic count.
+// One FMA per tensor element and one per inner result: the algorithmic count.  (Tried and dropped: fetching
+// row i + 1 into a second SGPR set while row i is multiplied -- scalar loads return out of order, every wait
+// is lgkmcnt(0), and the ping-pong version was 0-15 % slower on 8^3 ... 16^3; the waves of other workgroups
+// hide the load latency better.)
 // 64 threads per workgroup; dynamic LDS = (sum of outer n) * 64 * 8 bytes.
 // ---------------------------------------------------------------------------------
 #define PCX_PLAIN_PAD 64
@@ -669,8 +672,15 @@ __device__ __forceinline__ void bary_weights_prod(double x, double scale, const 
     for (int j = 0; j < n; ++j) dst[j * stride] *= r;
 }
 
+// The tensor is read through a CONSTANT-address-space pointer: it is never written while an evaluation
+// kernel runs, and with a wave-uniform address that is what lets hipcc use scalar loads (s_load into
+// SGPRs) whatever it can or cannot prove about aliasing with `out` (a tensor pointer fetched from a
+// multi-spec table carries no noalias information and fell back to 64-lane flat loads).
+typedef const double __attribute__((address_space(4))) *pcx_cptr;
+__device__ __forceinline__ pcx_cptr pcx_as_constant(const double *p) { return (pcx_cptr)(unsigned long long)p; }
+
 template <int LEVEL, int DOUT, int NLP>
-__device__ __forceinline__ double bary_small_nest(const BaryDims &dims, const double *__restrict__ Tb,
+__device__ __forceinline__ double bary_small_nest(const BaryDims &dims, pcx_cptr Tb,
                                                   const double *bw_lane, const double (&bl)[NLP]) {
     if constexpr (LEVEL == DOUT) {
         double s = 0.0;
@@ -720,11 +730,11 @@ k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes
     }
     // the table is wave-private (one wave per workgroup): no barrier
     if (T_tab == nullptr) {
-        const double y = bary_small_nest<0, DOUT, NLP>(dims, T, bw_lane, bl);
+        const double y = bary_small_nest<0, DOUT, NLP>(dims, pcx_as_constant(T), bw_lane, bl);
         if (valid) out[row * ostride + ooff] = y;
     } else {
         for (int z = 0; z < m; ++z) {
-            const double y = bary_small_nest<0, DOUT, NLP>(dims, T_tab[z], bw_lane, bl);
+            const double y = bary_small_nest<0, DOUT, NLP>(dims, pcx_as_constant(T_tab[z]), bw_lane, bl);
             if (valid) out[row * ostride + ooff + z] = y;
         }
     }

@@ -29,7 +29,16 @@ for it in range(60):
     sp = ChebyshevSpline.from_values([rng.standard_normal((5, 4)) for _ in range(4)], 2, [[0, 1], [0, 1]], [5, 4], [[0.5], [0.3]])
     sp.eval_batch(rng.uniform(0, 1, (1000, 2)), [0, 0])
     ChebyshevTT.from_values(rng.standard_normal((6, 5, 4)), 3, [[0, 1]] * 3, [6, 5, 4]).eval([0.1, 0.2, 0.3])
-    del c, tt, big, sp
+    # round 2: the lane-per-point kernel, and a handle driven past its derivative-tensor cache (LRU eviction)
+    sm = ChebyshevApproximation.from_values(rng.standard_normal((12, 12)), 2, [[0, 1]] * 2, [12, 12])
+    sm.vectorized_eval_multi_batch(rng.uniform(0, 1, (5000, 2)), [[0, 0], [1, 0], [0, 2]])
+    ev = ChebyshevApproximation.from_values(rng.standard_normal((40, 40, 40)), 3, [[0, 1]] * 3, [40, 40, 40])
+    p3 = rng.uniform(0, 1, (64, 3))
+    for a in range(5):
+        for b in range(5):
+            for cc in range(5):
+                ev.vectorized_eval_batch(p3, [a, b, cc])           # 125 specs > 96 cached: evictions free 0.5 MB + fragments each
+    del c, tt, big, sp, sm, ev
     gc.collect()
     if it == 4:
         start = free_mb()
