@@ -117,6 +117,29 @@ def test_bench_launches_two_ranks_itself():
     assert "cpu_baseline" not in line                       # rank 0 at N = 1 only
 
 
+def test_bench_under_the_driver_launcher():
+    """How the driver starts the multi-GPU bench: `python -m torch.distributed.run --nproc-per-node N
+    bench.py --gpus N` (torch only launches the processes; the ranks never import it).  Two ranks, both
+    on GPU 0 here."""
+    import socket
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = str(sock.getsockname()[1])
+    env = dict(os.environ, PCX_BENCH_SHARE_DEVICE="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "PCX_RDZV_DIR"):
+        env.pop(k, None)
+    res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", port, os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "200000", "--no-companion"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["comm"]["torch"] is False
+    assert line["gather"]["d2h"]["value"] > 0 and len(line["roofline"]["avg_launch_ms_per_rank"]) == 2
+
+
 def test_eval_sharded_two_ranks_on_one_gpu(tmp_path):
     """eval_sharded with the HIP evaluator: two processes, one GPU, result = one-process result."""
     worker = tmp_path / "w.py"
