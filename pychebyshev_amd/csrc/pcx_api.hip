@@ -1819,7 +1819,7 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
     struct Release { Scratch &a, &b, &c, &d; ~Release() { a.release(); b.release(); c.release(); d.release(); } } rel{sU, snrm, srows, sG};
     if ((rc = cur.alloc((size_t)total * sizeof(double)))) return rc;
     if ((rc = nxt.alloc((size_t)total * sizeof(double)))) return rc;
-    if ((rc = drot.alloc(sizeof(int)))) return rc;
+    if ((rc = drot.alloc(2 * sizeof(int)))) return rc;      // {pairs rotated, pairs rotated that were > 1e-8 from orthogonal}
     HIP_TRY(hipMemcpy(cur.p, tensor, (size_t)total * sizeof(double), hipMemcpyHostToDevice));
     long elems = total;
     int r_prev = 1;
@@ -1891,15 +1891,15 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
             if (mp - 1 <= 16) {
                 // a short tournament (the 11-row first unfolding): plain launches, no graph to build
                 for (int sweep = 0; sweep < 60; ++sweep) {
-                    HIP_TRY(hipMemsetAsync(drot.p, 0, sizeof(int), 0));
+                    HIP_TRY(hipMemsetAsync(drot.p, 0, 2 * sizeof(int), 0));
                     for (int step = 0; step < mp - 1; ++step)
                         hipLaunchKernelGGL(k_rowjacobi_step, dim3(mp / 2), dim3(TTSVD_THREADS), 0, 0, cur.as<double>(), N, m, N,
                                            U.as<double>(), step, drot.as<int>(), floor2, rot_tol, sig2);
                     HIP_TRY(hipGetLastError());
-                    int rotated = 0;
-                    HIP_TRY(hipMemcpy(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost));
+                    int rotated[2] = {0, 0};
+                    HIP_TRY(hipMemcpy(rotated, drot.p, 2 * sizeof(int), hipMemcpyDeviceToHost));
                     ++sweeps_total;
-                    if (rotated == 0) break;
+                    if (rotated[1] == 0) break;
                 }
             } else {
             hipStream_t cs = nullptr;
@@ -1922,14 +1922,14 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
             if (ge == hipSuccess) ge = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
             if (ge != hipSuccess) { cleanup(); return fail(PCX_ERR_HIP, "TT-SVD sweep graph: %s", hipGetErrorString(ge)); }
             for (int sweep = 0; sweep < 60; ++sweep) {
-                int rotated = 0;
-                hipError_t e = hipMemsetAsync(drot.p, 0, sizeof(int), cs);
+                int rotated[2] = {0, 0};
+                hipError_t e = hipMemsetAsync(drot.p, 0, 2 * sizeof(int), cs);
                 if (e == hipSuccess) e = hipGraphLaunch(exec, cs);
-                if (e == hipSuccess) e = hipMemcpyAsync(&rotated, drot.p, sizeof(int), hipMemcpyDeviceToHost, cs);
+                if (e == hipSuccess) e = hipMemcpyAsync(rotated, drot.p, 2 * sizeof(int), hipMemcpyDeviceToHost, cs);
                 if (e == hipSuccess) e = hipStreamSynchronize(cs);
                 if (e != hipSuccess) { cleanup(); return fail(PCX_ERR_HIP, "TT-SVD sweep: %s", hipGetErrorString(e)); }
                 ++sweeps_total;
-                if (rotated == 0) break;
+                if (rotated[1] == 0) break;
             }
             cleanup();
             }

@@ -71,6 +71,10 @@ k_rowjacobi_step(double *__restrict__ B, long ldb, int m, long N, double *__rest
     if (!(aa > floor2) || !(bb > floor2)) return;
     if (aa < sig2 && bb < sig2) return;      // two rows far below the truncation threshold: both will be dropped
     if (ab * ab <= (rot_tol * rot_tol) * aa * bb) return;          // |a.b| <= rot_tol |a||b| without two square roots
+    // rotated[1] counts the pairs that were further than 1e-8 from orthogonal: a sweep without any leaves
+    // every pair below ~1e-16 (the iteration converges quadratically), so it is the last one -- no extra
+    // sweep just to see zero rotations
+    const bool large = ab * ab > 1e-16 * aa * bb;
     const double zeta = (bb - aa) / (2.0 * ab);
     const double t = __builtin_copysign(1.0, zeta) / (__builtin_fabs(zeta) + __builtin_sqrt(1.0 + zeta * zeta));
     const double c = 1.0 / __builtin_sqrt(1.0 + t * t);
@@ -85,7 +89,10 @@ k_rowjacobi_step(double *__restrict__ B, long ldb, int m, long N, double *__rest
         U[(long)r * m + p] = c * x - s * y;
         U[(long)r * m + q] = s * x + c * y;
     }
-    if (threadIdx.x == 0) atomicAdd(rotated, 1);
+    if (threadIdx.x == 0) {
+        atomicAdd(rotated, 1);
+        if (large) atomicAdd(rotated + 1, 1);
+    }
 }
 
 // The whole iteration in ONE workgroup for unfoldings that fit LDS (the later, small ones of a
@@ -100,7 +107,7 @@ __global__ void __launch_bounds__(TTSVD_LDS_THREADS)
 k_rowjacobi_lds(double *__restrict__ Bg, int m, int N, double *__restrict__ Ug, double floor2, double rot_tol,
                 double sig2, int max_sweeps, int *__restrict__ sweeps_out, int u_in_lds) {
     extern __shared__ double rows[];               // m x N, row stride N (+ m x m for U when it fits)
-    __shared__ int rotated;
+    __shared__ int rotated, rotated_large;
     const int tid = threadIdx.x;
     for (long i = tid; i < (long)m * N; i += TTSVD_LDS_THREADS) rows[i] = Bg[i];
     double *U = Ug;
@@ -112,7 +119,7 @@ k_rowjacobi_lds(double *__restrict__ Bg, int m, int N, double *__restrict__ Ug, 
     const int mp = (m + 1) & ~1;
     int sweep = 0;
     for (; sweep < max_sweeps; ++sweep) {
-        if (tid == 0) rotated = 0;
+        if (tid == 0) { rotated = 0; rotated_large = 0; }
         __syncthreads();
         for (int step = 0; step < mp - 1; ++step) {
             // a row pair per 16-lane group (64 groups): the 44 pairs of an 88-row step run in ONE round,
@@ -141,6 +148,7 @@ k_rowjacobi_lds(double *__restrict__ Bg, int m, int N, double *__restrict__ Ug, 
                 if (!(aa > floor2) || !(bb > floor2)) continue;
                 if (aa < sig2 && bb < sig2) continue;
                 if (ab * ab <= (rot_tol * rot_tol) * aa * bb) continue;
+                const bool large = ab * ab > 1e-16 * aa * bb;
                 const double zeta = (bb - aa) / (2.0 * ab);
                 const double t = __builtin_copysign(1.0, zeta) / (__builtin_fabs(zeta) + __builtin_sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / __builtin_sqrt(1.0 + t * t);
@@ -155,11 +163,11 @@ k_rowjacobi_lds(double *__restrict__ Bg, int m, int N, double *__restrict__ Ug, 
                     U[(long)r * m + p] = c * x - sn * y;
                     U[(long)r * m + q] = sn * x + c * y;
                 }
-                if (l16 == 0) atomicAdd(&rotated, 1);
+                if (l16 == 0) { atomicAdd(&rotated, 1); if (large) atomicAdd(&rotated_large, 1); }
             }
             __syncthreads();
         }
-        const int done = (rotated == 0);
+        const int done = (rotated_large == 0);     // see k_rowjacobi_step: the sweep just finished was the last
         __syncthreads();
         if (done) { ++sweep; break; }
     }
@@ -226,7 +234,8 @@ k_symjacobi_lds(const double *__restrict__ Gg, int m, double *__restrict__ Vg, d
                         const double t = __builtin_copysign(1.0, zeta) / (__builtin_fabs(zeta) + __builtin_sqrt(1.0 + zeta * zeta));
                         c = 1.0 / __builtin_sqrt(1.0 + t * t);
                         sn = c * t;
-                        atomicAdd(&rotated, 1);
+                        // only rotations further than sqrt(rot_tol) from orthogonal call for another sweep
+                        if (ab * ab > rot_tol * aa * bb) atomicAdd(&rotated, 1);
                     }
                 } else { p = q = -1; }
                 cs[2 * i] = c; cs[2 * i + 1] = sn; pq[2 * i] = p; pq[2 * i + 1] = q;
