@@ -376,11 +376,29 @@ def run_rank(args) -> int:
         raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} HIP device(s) visible")
 
     comm, rccl_error = None, None
+    stuck_init = False
     if group is not None and not share_device:
-        try:
-            comm = RcclComm(group, dev)
-        except Exception as exc:                                  # reported on the line, never silent
-            rccl_error = f"{type(exc).__name__}: {exc}"
+        # ncclCommInitRank is collective: if it never returns (a rank that died, a fabric problem) the bench
+        # would hang without a line.  Bootstrap on a helper thread with a deadline; past it the run goes on
+        # with the host-memory gather and says so on the line.
+        import threading
+        box = {}
+
+        def bootstrap():
+            try:
+                box["comm"] = RcclComm(group, dev)
+            except Exception as exc:                              # reported on the line, never silent
+                box["error"] = f"{type(exc).__name__}: {exc}"
+
+        th = threading.Thread(target=bootstrap, daemon=True)
+        th.start()
+        deadline = float(os.environ.get("PCX_BENCH_RCCL_TIMEOUT", "180"))
+        th.join(deadline)
+        if th.is_alive():
+            stuck_init = True
+            rccl_error = f"RCCL initialisation did not finish within {deadline:g} s"
+        else:
+            comm, rccl_error = box.get("comm"), box.get("error")
         flags = group.gather_floats(0.0 if comm is not None else 1.0)
         if any(flags) and comm is not None:                       # a communicator on some ranks only is useless
             comm.close()
@@ -717,6 +735,9 @@ def run_rank(args) -> int:
         comm.close()
     if group is not None:
         group.close()
+    if stuck_init:                            # a thread is still inside librccl: leave without joining it
+        sys.stderr.flush()
+        os._exit(0)
     return 0
 
 

@@ -106,6 +106,16 @@ def test_bench_single_rank_with_rccl_forced():
     assert 0 < line["roofline"]["frac"] < 1
 
 
+def test_bench_goes_on_when_the_rccl_bootstrap_misses_its_deadline():
+    """A communicator that is not there in time (deadline 0 here) must not hang the bench: the step falls
+    back to the host-memory gather and the line says why."""
+    line = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--points", "200000", "--no-companion",
+                   "--no-cpu-baseline"], {"PCX_BENCH_FORCE_COMM": "1", "PCX_BENCH_RCCL_TIMEOUT": "0"})
+    assert line["config"]["gather"] == "d2h" and line["comm"]["backend"] is None
+    assert "did not finish" in line["comm"]["rccl_error"]
+    assert line["gather"]["d2h"]["value"] > 0 and "rccl" not in line["gather"]
+
+
 def test_bench_launches_two_ranks_itself():
     """Plain `python bench.py --gpus 2`: the script starts the ranks (both on GPU 0 here)."""
     line = _bench(["--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "200000", "--no-companion"],
