@@ -47,6 +47,7 @@ extern "C" {
 typedef struct pcx_bary pcx_bary; /* device-resident ChebyshevApproximation state */
 typedef struct pcx_tt pcx_tt;     /* device-resident ChebyshevTT coefficient cores */
 typedef struct pcx_spline pcx_spline; /* knots + piece handles of a ChebyshevSpline   */
+typedef struct pcx_slider pcx_slider; /* partition + slide handles of a ChebyshevSlider */
 
 /* ---- library / device ------------------------------------------------------ */
 int pcx_abi_version(void);
@@ -154,6 +155,35 @@ int pcx_spline_eval_multi_batch(pcx_spline *h, const double *pts, int64_t N, con
                                 int m, double *out);
 /* The piece index of every point (spline.py:414-446, _find_piece) -- for tests/tools.  */
 int pcx_spline_piece_ids(pcx_spline *h, const double *pts, int64_t N, int32_t *ids_out);
+/* Device-resident points (N x d) and results (N, or N x m) on the handle's device.  Routing needs
+ * the per-piece counts on the host, so these calls are synchronous: all work is done on return;
+ * m <= 64. */
+int pcx_spline_eval_batch_dev(pcx_spline *h, const double *d_pts, int64_t N, const int32_t *deriv,
+                              double *d_out);
+int pcx_spline_eval_multi_batch_dev(pcx_spline *h, const double *d_pts, int64_t N,
+                                    const int32_t *derivs, int m, double *d_out);
+
+/* ---- slider: sum of low-dimensional slides around a pivot -------------------- */
+/* State of ChebyshevSlider (slider.py:80-341): the slides are barycentric handles over the
+ * dimension groups of `partition` (group_sizes[s] entries of group_dims_cat each, every
+ * dimension exactly once), pivot_value = f(pivot_point).  The slides are BORROWED: they must
+ * outlive the slider handle.  Evaluation (slider.py:247-318, eq. 7.5 of Ruiz & Zeron):
+ *   value:       pivot + sum_s (slide_s(x_group_s) - pivot), summed in slide order;
+ *   derivative:  all differentiated dimensions in one slide -> that slide's derivative;
+ *                spread over more than one slide -> 0.
+ * The reference evaluates one point per call; these evaluate N points with one launch per
+ * slide (plus a column gather and the sum), points uploaded once for all m specs. */
+int pcx_slider_create(int device, int d, int n_slides, pcx_bary *const *slides,
+                      const int32_t *group_sizes, const int32_t *group_dims_cat,
+                      double pivot_value, pcx_slider **out);
+int pcx_slider_destroy(pcx_slider *h);
+int pcx_slider_eval_batch(pcx_slider *h, const double *pts, int64_t N, const int32_t *deriv,
+                          double *out);
+int pcx_slider_eval_multi_batch(pcx_slider *h, const double *pts, int64_t N,
+                                const int32_t *derivs, int m, double *out /* N x m */);
+/* Device-resident points and results; synchronous on return. */
+int pcx_slider_eval_multi_batch_dev(pcx_slider *h, const double *d_pts, int64_t N,
+                                    const int32_t *derivs, int m, double *d_out);
 
 /* ---- tensor-train interpolant ---------------------------------------------- */
 /* State of ChebyshevTT (tensor_train.py:1117-1138): Chebyshev COEFFICIENT cores

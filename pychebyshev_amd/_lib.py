@@ -85,6 +85,13 @@ SIGNATURES = {
     "pcx_spline_eval_batch": (_I, [_V, c_f64p, _L, c_i32p, c_f64p]),
     "pcx_spline_eval_multi_batch": (_I, [_V, c_f64p, _L, c_i32p, _I, c_f64p]),
     "pcx_spline_piece_ids": (_I, [_V, c_f64p, _L, c_i32p]),
+    "pcx_spline_eval_batch_dev": (_I, [_V, _V, _L, c_i32p, _V]),
+    "pcx_spline_eval_multi_batch_dev": (_I, [_V, _V, _L, c_i32p, _I, _V]),
+    "pcx_slider_create": (_I, [_I, _I, _I, c_vpp, c_i32p, c_i32p, _D, c_vpp]),
+    "pcx_slider_destroy": (_I, [_V]),
+    "pcx_slider_eval_batch": (_I, [_V, c_f64p, _L, c_i32p, c_f64p]),
+    "pcx_slider_eval_multi_batch": (_I, [_V, c_f64p, _L, c_i32p, _I, c_f64p]),
+    "pcx_slider_eval_multi_batch_dev": (_I, [_V, _V, _L, c_i32p, _I, _V]),
     "pcx_tt_create": (_I, [_I, _I, c_i32p, c_i32p, c_f64p, c_f64p, c_f64p, c_i32p, c_vpp]),
     "pcx_tt_destroy": (_I, [_V]),
     "pcx_tt_eval_batch": (_I, [_V, c_f64p, _L, c_f64p]),

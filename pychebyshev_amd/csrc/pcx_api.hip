@@ -1139,6 +1139,7 @@ struct pcx_spline {
     std::vector<pcx_bary *> pieces;      // borrowed
     double *d_knots = nullptr;
     int *d_counts = nullptr;             // n_pieces: histogram, then bucket cursors
+    int lds_hist = 1;                    // routing kernels count per workgroup in LDS (<= PCX_SPLINE_LDS_PIECES pieces)
     std::mutex mu;
     Scratch s_pts, s_out, s_piece, s_perm, s_partial;
 };
@@ -1187,6 +1188,10 @@ extern "C" int pcx_spline_create(int device, int d, const int32_t *n_knots, cons
         h->pieces.push_back(pieces[i]);
     }
     h->n_pieces = n_pieces;
+    {   // PCX_SPLINE_GLOBAL_HIST=1 forces the many-pieces routing path (tests)
+        const char *g = getenv("PCX_SPLINE_GLOBAL_HIST");
+        h->lds_hist = (n_pieces <= PCX_SPLINE_LDS_PIECES && !(g && g[0] == '1')) ? 1 : 0;
+    }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_knots, (nk_total ? nk_total : 1) * sizeof(double));
     if (e == hipSuccess && nk_total) e = hipMemcpy(h->d_knots, knots_cat, nk_total * sizeof(double), hipMemcpyHostToDevice);
@@ -1206,8 +1211,10 @@ static int spline_bucket(pcx_spline *h, const double *dp, long cnt, std::vector<
     if (rc) return rc;
     int *piece = (int *)h->s_piece.ptr, *perm = (int *)h->s_perm.ptr;
     HIP_TRY(hipMemsetAsync(h->d_counts, 0, (size_t)h->n_pieces * sizeof(int), h->stream));
-    unsigned blocks = (unsigned)((cnt + 255) / 256);
-    hipLaunchKernelGGL(k_spline_piece_id, dim3(blocks), dim3(256), 0, h->stream, h->sd, h->d_knots, dp, cnt, piece, h->d_counts);
+    const unsigned blocks = (unsigned)((cnt + PCX_SPLINE_BLOCK_POINTS - 1) / PCX_SPLINE_BLOCK_POINTS);
+    const int lds_hist = h->lds_hist;
+    hipLaunchKernelGGL(k_spline_piece_id, dim3(blocks), dim3(256), 0, h->stream, h->sd, h->d_knots, dp, cnt, piece, h->d_counts,
+                       h->n_pieces, lds_hist);
     HIP_TRY(hipGetLastError());
     counts.assign(h->n_pieces, 0);
     HIP_TRY(hipMemcpyAsync(counts.data(), h->d_counts, (size_t)h->n_pieces * sizeof(int), hipMemcpyDeviceToHost, h->stream));
@@ -1216,9 +1223,46 @@ static int spline_bucket(pcx_spline *h, const double *dp, long cnt, std::vector<
     int acc = 0;
     for (int i = 0; i < h->n_pieces; ++i) { offsets[i] = acc; acc += counts[i]; }
     HIP_TRY(hipMemcpyAsync(h->d_counts, offsets.data(), (size_t)h->n_pieces * sizeof(int), hipMemcpyHostToDevice, h->stream));
-    hipLaunchKernelGGL(k_spline_scatter, dim3(blocks), dim3(256), 0, h->stream, piece, cnt, h->d_counts, perm);
+    hipLaunchKernelGGL(k_spline_scatter, dim3(blocks), dim3(256), 0, h->stream, piece, cnt, h->d_counts, perm, h->n_pieces, lds_hist);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(h->stream));   // `offsets` (pageable) must stay valid until copied
+    return PCX_OK;
+}
+
+// One chunk of device-resident points through routing, bucketing and the per-piece launches, on h->stream
+// (results land in dout in point order; the launches are queued, not awaited).  Caller holds h->mu.
+static int spline_eval_chunk(pcx_spline *h, const double *dp, long cnt, const int32_t *derivs, int m, double *dout) {
+    const int d = h->sd.d;
+    std::vector<int> counts, offsets;
+    int rc = spline_bucket(h, dp, cnt, counts, offsets);
+    if (rc) return rc;
+    const int *perm = (const int *)h->s_perm.ptr;
+    for (int i = 0; i < h->n_pieces; ++i) {
+        if (counts[i] == 0) continue;
+        pcx_bary *pc = h->pieces[i];
+        std::lock_guard<std::mutex> plk(pc->mu);
+        pc->call_mark = pc->clock;
+        std::vector<DerivedTensor *> dts(m);
+        for (int s = 0; s < m; ++s) {
+            rc = bary_get_tensor(pc, derivs ? derivs + (size_t)s * d : nullptr, &dts[s]);
+            if (rc) return rc;
+        }
+        const double *const *frag_tab = dts[0]->slot;
+        const int eff = bary_effective_variant(pc);
+        if (m > 1 && (eff == 4 || pc->mfma_ok)) {
+            std::vector<double *> tab(m);
+            for (int s = 0; s < m; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
+            if (tab != pc->tab_host) {
+                HIP_TRY(hipStreamSynchronize(h->stream));   // earlier launches may still read d_tab
+                HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+                pc->tab_host = tab;
+            }
+            frag_tab = pc->d_tab;
+        }
+        rc = bary_launch(pc, dts.data(), m, frag_tab, dp, counts[i], dout, m, 0, h->stream, &h->s_partial,
+                         perm + offsets[i]);
+        if (rc) return rc;
+    }
     return PCX_OK;
 }
 
@@ -1251,40 +1295,41 @@ static int spline_eval_host(pcx_spline *h, const double *pts, int64_t N, const i
         if (rc) return rc;
         double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
         HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        std::vector<int> counts, offsets;
-        rc = spline_bucket(h, dp, cnt, counts, offsets);
+        rc = spline_eval_chunk(h, dp, cnt, derivs, m, dout);
         if (rc) return rc;
-        const int *perm = (const int *)h->s_perm.ptr;
-        for (int i = 0; i < h->n_pieces; ++i) {
-            if (counts[i] == 0) continue;
-            pcx_bary *pc = h->pieces[i];
-            std::lock_guard<std::mutex> plk(pc->mu);
-            pc->call_mark = pc->clock;
-            std::vector<DerivedTensor *> dts(m);
-            for (int s = 0; s < m; ++s) {
-                rc = bary_get_tensor(pc, derivs ? derivs + (size_t)s * d : nullptr, &dts[s]);
-                if (rc) return rc;
-            }
-            const double *const *frag_tab = dts[0]->slot;
-            const int eff = bary_effective_variant(pc);
-            if (m > 1 && (eff == 4 || pc->mfma_ok)) {
-                std::vector<double *> tab(m);
-                for (int s = 0; s < m; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
-                if (tab != pc->tab_host) {
-                    HIP_TRY(hipStreamSynchronize(h->stream));   // earlier launches may still read d_tab
-                    HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
-                    pc->tab_host = tab;
-                }
-                frag_tab = pc->d_tab;
-            }
-            rc = bary_launch(pc, dts.data(), m, frag_tab, dp, counts[i], dout, m, 0, h->stream, &h->s_partial,
-                             perm + offsets[i]);
-            if (rc) return rc;
-        }
         HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return PCX_OK;
+}
+
+// Device-resident points and results (d_pts N x d, d_out N x m, both on the handle's device).  Routing needs
+// the per-piece counts on the host, so the call is synchronous: everything has finished when it returns.
+static int spline_eval_dev(pcx_spline *h, const double *d_pts, int64_t N, const int32_t *derivs, int m, double *d_out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1 || m > kMaxSpecs) return fail(PCX_ERR_INVALID, "bad N, or m outside [1, %d]", kMaxSpecs);
+    if (N > 0 && (!d_pts || !d_out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int d = h->sd.d;
+    for (int64_t start = 0; start < N; start += kChunkPoints) {
+        long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
+        int rc = spline_eval_chunk(h, d_pts + (size_t)start * d, cnt, derivs, m, d_out + (size_t)start * m);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return PCX_OK;
+}
+
+extern "C" int pcx_spline_eval_batch_dev(pcx_spline *h, const double *d_pts, int64_t N, const int32_t *deriv,
+                                         double *d_out) {
+    return spline_eval_dev(h, d_pts, N, deriv, 1, d_out);
+}
+
+extern "C" int pcx_spline_eval_multi_batch_dev(pcx_spline *h, const double *d_pts, int64_t N,
+                                               const int32_t *derivs, int m, double *d_out) {
+    if (!derivs) return fail(PCX_ERR_INVALID, "derivs is NULL");
+    return spline_eval_dev(h, d_pts, N, derivs, m, d_out);
 }
 
 extern "C" int pcx_spline_eval_batch(pcx_spline *h, const double *pts, int64_t N, const int32_t *deriv,
@@ -1314,6 +1359,185 @@ extern "C" int pcx_spline_piece_ids(pcx_spline *h, const double *pts, int64_t N,
     rc = spline_bucket(h, (const double *)h->s_pts.ptr, (long)N, counts, offsets);
     if (rc) return rc;
     HIP_TRY(hipMemcpy(ids_out, h->s_piece.ptr, (size_t)N * sizeof(int), hipMemcpyDeviceToHost));
+    return PCX_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// slider handle (reference slider.py:80-341): slides are borrowed pcx_bary handles
+// ---------------------------------------------------------------------------------
+struct pcx_slider {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int d = 0;
+    double pivot = 0.0;
+    std::vector<pcx_bary *> slides;      // borrowed
+    std::vector<SliderCols> cols;        // the point columns slide s reads
+    std::vector<int> owner;              // dimension -> slide
+    int max_cols = 1;
+    std::mutex mu;
+    Scratch s_pts, s_out, s_cols, s_vals, s_partial;
+};
+
+extern "C" int pcx_slider_destroy(pcx_slider *h) {
+    if (!h) return PCX_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    h->s_pts.release(); h->s_out.release(); h->s_cols.release(); h->s_vals.release(); h->s_partial.release();
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return PCX_OK;
+}
+
+extern "C" int pcx_slider_create(int device, int d, int n_slides, pcx_bary *const *slides,
+                                 const int32_t *group_sizes, const int32_t *group_dims_cat, double pivot_value,
+                                 pcx_slider **out) {
+    if (!out) return fail(PCX_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (d < 1 || d > 4096 || n_slides < 1 || !slides || !group_sizes || !group_dims_cat)
+        return fail(PCX_ERR_INVALID, "bad argument");
+    int rc = use_device(device);
+    if (rc) return rc;
+    pcx_slider *h = new (std::nothrow) pcx_slider();
+    if (!h) return fail(PCX_ERR_NOMEM, "out of host memory");
+    h->device = device;
+    h->d = d;
+    h->pivot = pivot_value;
+    h->owner.assign(d, -1);
+    long at = 0;
+    for (int s = 0; s < n_slides; ++s) {
+        const int g = group_sizes[s];
+        if (g < 1 || g > PCX_MAX_DIMS) { delete h; return fail(PCX_ERR_INVALID, "slide %d has %d dimensions (1..%d)", s, g, PCX_MAX_DIMS); }
+        if (!slides[s] || slides[s]->device != device || slides[s]->dims.d != g) { delete h; return fail(PCX_ERR_INVALID, "slide %d is NULL, on another device or not %d-dimensional", s, g); }
+        SliderCols c;
+        c.nc = g;
+        for (int k = 0; k < PCX_MAX_DIMS; ++k) c.col[k] = 0;
+        for (int k = 0; k < g; ++k) {
+            const int dim = group_dims_cat[at + k];
+            if (dim < 0 || dim >= d || h->owner[dim] != -1) { delete h; return fail(PCX_ERR_INVALID, "partition must cover each dimension exactly once (slide %d, entry %d)", s, k); }
+            h->owner[dim] = s;
+            c.col[k] = dim;
+        }
+        at += g;
+        h->slides.push_back(slides[s]);
+        h->cols.push_back(c);
+        h->max_cols = std::max(h->max_cols, g);
+    }
+    for (int k = 0; k < d; ++k)
+        if (h->owner[k] < 0) { delete h; return fail(PCX_ERR_INVALID, "partition must cover each dimension exactly once (dimension %d missing)", k); }
+    hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { int c = fail(PCX_ERR_HIP, "slider create: %s", hipGetErrorString(e)); pcx_slider_destroy(h); return c; }
+    *out = h;
+    return PCX_OK;
+}
+
+// slide s at the gathered columns of dp, spec `sub` (the slide's own dimensions), into dout[p * ostride + ooff]
+static int slider_launch_slide(pcx_slider *h, int s, const double *dp, long cnt, const int32_t *sub, double *dout,
+                               long ostride, long ooff) {
+    pcx_bary *pc = h->slides[s];
+    const SliderCols &c = h->cols[s];
+    double *cols = (double *)h->s_cols.ptr;
+    const long elems = cnt * c.nc;
+    hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, h->stream, dp, cnt, h->d, c, cols);
+    HIP_TRY(hipGetLastError());
+    std::lock_guard<std::mutex> plk(pc->mu);
+    pc->call_mark = pc->clock;
+    DerivedTensor *dt = nullptr;
+    int rc = bary_get_tensor(pc, sub, &dt);
+    if (rc) return rc;
+    return bary_launch(pc, &dt, 1, dt->slot, cols, cnt, dout, ostride, ooff, h->stream, &h->s_partial);
+}
+
+// One chunk of device-resident points, m specs, results into dout (cnt x m); queued on h->stream.
+static int slider_eval_chunk(pcx_slider *h, const double *dp, long cnt, const int32_t *derivs, int m, double *dout) {
+    const int ns = (int)h->slides.size();
+    int rc = h->s_cols.reserve((size_t)cnt * h->max_cols * sizeof(double));
+    if (rc) return rc;
+    const unsigned blocks = (unsigned)((cnt + 255) / 256);
+    bool have_values = false;
+    for (int q = 0; q < m; ++q) {
+        const int32_t *spec = derivs ? derivs + (size_t)q * h->d : nullptr;
+        // the slides that own a differentiated dimension: more than one -> the mixed partial is identically zero
+        int active = -1, n_active = 0;
+        if (spec)
+            for (int k = 0; k < h->d; ++k) {
+                if (spec[k] < 0) return fail(PCX_ERR_INVALID, "derivative order %d at dim %d", spec[k], k);
+                if (spec[k] > 0 && h->owner[k] != active) {
+                    bool counted = false;
+                    for (int j = 0; j < k; ++j) counted = counted || (spec[j] > 0 && h->owner[j] == h->owner[k]);
+                    if (!counted) ++n_active;
+                    active = h->owner[k];
+                }
+            }
+        if (n_active > 1) {
+            hipLaunchKernelGGL(k_fill_strided, dim3(blocks), dim3(256), 0, h->stream, dout, cnt, (long)m, (long)q, 0.0);
+            HIP_TRY(hipGetLastError());
+        } else if (n_active == 1) {
+            int32_t sub[PCX_MAX_DIMS];
+            for (int k = 0; k < h->cols[active].nc; ++k) sub[k] = spec[h->cols[active].col[k]];
+            rc = slider_launch_slide(h, active, dp, cnt, sub, dout, m, q);
+            if (rc) return rc;
+        } else {
+            if (!have_values) {            // the slides' values are shared by every value spec of the call
+                rc = h->s_vals.reserve((size_t)cnt * ns * sizeof(double));
+                if (rc) return rc;
+                for (int s = 0; s < ns; ++s) {
+                    rc = slider_launch_slide(h, s, dp, cnt, nullptr, (double *)h->s_vals.ptr, ns, s);
+                    if (rc) return rc;
+                }
+                have_values = true;
+            }
+            hipLaunchKernelGGL(k_slider_sum, dim3(blocks), dim3(256), 0, h->stream, (const double *)h->s_vals.ptr, cnt, ns,
+                               h->pivot, dout, (long)m, (long)q);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return PCX_OK;
+}
+
+extern "C" int pcx_slider_eval_multi_batch(pcx_slider *h, const double *pts, int64_t N, const int32_t *derivs, int m,
+                                           double *out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (N == 0) return PCX_OK;
+    if (!pts || !out) return fail(PCX_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    const int64_t chunk = std::max<int64_t>(1, kChunkPoints / std::max(1, m));
+    for (int64_t start = 0; start < N; start += chunk) {
+        const long cnt = (long)std::min<int64_t>(chunk, N - start);
+        int rc = h->s_pts.reserve((size_t)cnt * h->d * sizeof(double));
+        if (rc) return rc;
+        rc = h->s_out.reserve((size_t)cnt * m * sizeof(double));
+        if (rc) return rc;
+        double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
+        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * h->d, (size_t)cnt * h->d * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        rc = slider_eval_chunk(h, dp, cnt, derivs, m, dout);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return PCX_OK;
+}
+
+extern "C" int pcx_slider_eval_batch(pcx_slider *h, const double *pts, int64_t N, const int32_t *deriv, double *out) {
+    return pcx_slider_eval_multi_batch(h, pts, N, deriv, 1, out);
+}
+
+// Device-resident points (N x d) and results (N x m); synchronous on return.
+extern "C" int pcx_slider_eval_multi_batch_dev(pcx_slider *h, const double *d_pts, int64_t N, const int32_t *derivs,
+                                               int m, double *d_out) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (N == 0) return PCX_OK;
+    if (!d_pts || !d_out) return fail(PCX_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    for (int64_t start = 0; start < N; start += kChunkPoints) {
+        const long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
+        int rc = slider_eval_chunk(h, d_pts + (size_t)start * h->d, cnt, derivs, m, d_out + (size_t)start * m);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
     return PCX_OK;
 }
 

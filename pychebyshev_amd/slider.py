@@ -9,13 +9,15 @@ v0.21.1) for the evaluation path:
     get_derivative_id, total_build_evals, pickle, repr
 
 ``eval_batch`` / ``eval_multi_batch`` are extensions (the reference has no batch method):
-every slide evaluates the whole batch in one device launch and the k slide results are
-added on the host in the reference's order.
+``pcx_slider_eval_multi_batch`` uploads the points once, every slide evaluates its column
+group of the whole batch in one device launch and a last kernel adds the slide results in
+the reference's order.
 
 Out of scope in this tier: algebra, calculus, extrude/slice, plotting.
 """
 from __future__ import annotations
 
+import ctypes
 import pickle
 import time
 import warnings
@@ -23,12 +25,48 @@ from typing import Callable, List, Sequence, Tuple
 
 import numpy as np
 
+from . import _lib
 from ._version import __version__
 from ._derivative_ids import DerivativeIdMixin
 from ._ergonomics import ErgonomicsMixin
 from .barycentric import ChebyshevApproximation
 
 __all__ = ["ChebyshevSlider"]
+
+
+class _DeviceSlider:
+    """Owner of one ``pcx_slider`` handle; keeps the slides' device models alive."""
+
+    def __init__(self, slider: "ChebyshevSlider", device: int):
+        lib = _lib.load()
+        self.models = []
+        for slide in slider.slides:
+            slide._device_index = device
+            self.models.append(slide._model())
+        sizes = _lib.i32([len(g) for g in slider.partition])
+        dims = _lib.i32([d for g in slider.partition for d in g])
+        arr = (ctypes.c_void_p * len(self.models))(*[m.handle for m in self.models])
+        handle = ctypes.c_void_p()
+        _lib.check(lib.pcx_slider_create(device, slider.num_dimensions, len(self.models),
+                                         ctypes.cast(arr, _lib.c_vpp), _lib.p_i32(sizes), _lib.p_i32(dims),
+                                         float(slider.pivot_value), ctypes.byref(handle)), lib)
+        self.lib = lib
+        self.handle = handle
+        self.device = device
+        self.tensors = [s.tensor_values for s in slider.slides]      # the arrays themselves, not their ids
+        self.pivot_value = float(slider.pivot_value)
+
+    def matches(self, slider: "ChebyshevSlider") -> bool:
+        return (len(self.tensors) == len(slider.slides) and self.pivot_value == float(slider.pivot_value)
+                and all(a is s.tensor_values for a, s in zip(self.tensors, slider.slides)))
+
+    def __del__(self):
+        try:
+            if self.handle:
+                self.lib.pcx_slider_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
 
 
 class ChebyshevSlider(ErgonomicsMixin, DerivativeIdMixin):
@@ -63,6 +101,24 @@ class ChebyshevSlider(ErgonomicsMixin, DerivativeIdMixin):
         self._cached_error_estimate = None
         self._derivative_id_registry: dict = {}
         self._derivative_id_to_orders: list = []
+        self._device_slider = None
+        self._device_index = None
+
+    # ---------------------------------------------------------------- device plumbing
+    def to_device(self, device: int | None = None) -> "ChebyshevSlider":
+        if not self._built:
+            raise RuntimeError("Call build() first")
+        dev = _lib.default_device() if device is None else int(device)
+        self._device_index = dev
+        self._device_slider = _DeviceSlider(self, dev)
+        return self
+
+    def _dev(self) -> _DeviceSlider:
+        s = self.__dict__.get("_device_slider")
+        if s is None or not s.matches(self):
+            self.to_device(self.__dict__.get("_device_index"))
+            s = self._device_slider
+        return s
 
     # ---------------------------------------------------------------- build
     def build(self, verbose: bool | int = True) -> None:
@@ -124,31 +180,25 @@ class ChebyshevSlider(ErgonomicsMixin, DerivativeIdMixin):
         return [self.eval(point, spec) for spec in derivative_orders]
 
     def eval_batch(self, points, derivative_order=None, *, derivative_id=None) -> np.ndarray:
-        """Batched :meth:`eval` (extension): each slide evaluates all N points in one launch."""
+        """Batched :meth:`eval` (extension): points uploaded once, one launch per slide, summed on the device."""
         if not self._built:
             raise RuntimeError("Call build() before eval_batch().")
         derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
-        pts = np.asarray(points, dtype=float)
-        if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
-            raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
-        active = self._active_slides(derivative_order)
-        if active:
-            if len(active) > 1:
-                return np.zeros(pts.shape[0])
-            idx = active.pop()
-            group = list(self.partition[idx])
-            return self.slides[idx].vectorized_eval_batch(np.ascontiguousarray(pts[:, group]),
-                                                          [derivative_order[d] for d in group])
-        result = np.full(pts.shape[0], float(self.pivot_value))
-        for idx, group in enumerate(self.partition):
-            group = list(group)
-            val = self.slides[idx].vectorized_eval_batch(np.ascontiguousarray(pts[:, group]), [0] * len(group))
-            result += val - self.pivot_value
-        return result
+        return self.eval_multi_batch(points, [list(derivative_order)])[:, 0]
 
     def eval_multi_batch(self, points, derivative_orders) -> np.ndarray:
-        """``(N, d)`` points x ``m`` specs -> ``(N, m)`` (extension)."""
-        return np.column_stack([self.eval_batch(points, list(spec)) for spec in derivative_orders])
+        """``(N, d)`` points x ``m`` specs -> ``(N, m)`` (extension); value specs share the slides' values."""
+        if not self._built:
+            raise RuntimeError("Call build() before eval_multi_batch().")
+        pts = _lib.f64(points)
+        if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
+            raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
+        specs = _lib.i32(np.asarray(derivative_orders).reshape(-1, self.num_dimensions))
+        s = self._dev()
+        out = np.empty((pts.shape[0], specs.shape[0]))
+        _lib.check(s.lib.pcx_slider_eval_multi_batch(s.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_i32(specs),
+                                                     specs.shape[0], _lib.p_f64(out)), s.lib)
+        return out
 
     # ---------------------------------------------------------------- misc
     @property
@@ -187,6 +237,7 @@ class ChebyshevSlider(ErgonomicsMixin, DerivativeIdMixin):
     def __getstate__(self) -> dict:
         state = self.__dict__.copy()
         state["function"] = None
+        state["_device_slider"] = None
         state["_pychebyshev_version"] = __version__
         return state
 

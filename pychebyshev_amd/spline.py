@@ -63,7 +63,11 @@ class _DeviceSpline:
         self.lib = lib
         self.handle = handle
         self.device = device
-        self.key = tuple(id(p.tensor_values) for p in spline._pieces)
+        self.tensors = [p.tensor_values for p in spline._pieces]      # the arrays themselves, not their ids
+
+    def matches(self, spline: "ChebyshevSpline") -> bool:
+        return (len(self.tensors) == len(spline._pieces)
+                and all(a is p.tensor_values for a, p in zip(self.tensors, spline._pieces)))
 
     def __del__(self):
         try:
@@ -311,7 +315,7 @@ class ChebyshevSpline(ErgonomicsMixin, DerivativeIdMixin):
 
     def _dev(self) -> _DeviceSpline:
         s = self._device_spline
-        if s is None or s.key != tuple(id(p.tensor_values) for p in self._pieces):
+        if s is None or not s.matches(self):
             self.to_device(self._device_index)
             s = self._device_spline
         return s

@@ -136,3 +136,67 @@ def test_spline_large_batch_and_empty_pieces(oracle_mod):
     d1 = sp.eval_batch(pts[sub], [1, 0, 0])
     assert_parity(d1, oracle_mod.spline_eval_batch(models, sp.knots, sp._shape, pts[sub], [1, 0, 0]), 1e-12,
                   "1M spline subset delta", float("inf"))
+
+
+@pytest.mark.gpu
+def test_spline_device_resident_entry_points_and_skewed_buckets():
+    """pcx_spline_eval[_multi]_batch_dev on device-resident points = the host-pointer calls bit for bit;
+    a batch that falls into ONE piece (every lane of every wave shares its bucket counter) and a batch
+    spread over all pieces are both bucketed completely."""
+    import ctypes
+    case = F.SPLINE_CASES["c"]
+    sp = _build(case)
+    rng = np.random.default_rng(17)
+    n = 300_007
+    pts = np.column_stack([rng.uniform(lo, hi, n) for lo, hi in case["domain"]])
+    one_piece = pts.copy()
+    for k, kn in enumerate(case["knots"]):
+        if kn:
+            one_piece[:, k] = rng.uniform(case["domain"][k][0], kn[0] - 1e-9, n)
+    assert set(np.unique(sp.piece_indices(one_piece))) == {0}
+    specs = [[0, 0, 0], [1, 0, 0], [0, 0, 1]]
+    s = sp._dev()
+    lib = s.lib
+    for batch in (pts, one_piece):
+        host1 = sp.eval_batch(batch, specs[1])
+        hostm = sp.eval_multi_batch(batch, specs)
+        assert np.array_equal(hostm[:, 1], host1)
+        # the per-piece results: evaluate every point with its own piece directly
+        ids = sp.piece_indices(batch)
+        direct = np.empty(n)
+        for p in np.unique(ids):
+            rows = np.nonzero(ids == p)[0]
+            direct[rows] = sp._pieces[p].vectorized_eval_batch(batch[rows], specs[1])
+        assert np.array_equal(direct, host1)
+        d_pts = ctypes.c_void_p()
+        d_out = ctypes.c_void_p()
+        _lib.check(lib.pcx_dev_malloc(0, batch.nbytes, ctypes.byref(d_pts)), lib)
+        _lib.check(lib.pcx_dev_malloc(0, n * 3 * 8, ctypes.byref(d_out)), lib)
+        _lib.check(lib.pcx_memcpy_h2d(0, d_pts, batch.ctypes.data_as(ctypes.c_void_p), batch.nbytes), lib)
+        _lib.check(lib.pcx_spline_eval_batch_dev(s.handle, d_pts, n, _lib.p_i32(_lib.i32(specs[1])), d_out), lib)
+        back = np.empty(n)
+        _lib.check(lib.pcx_memcpy_d2h(0, back.ctypes.data_as(ctypes.c_void_p), d_out, n * 8), lib)
+        assert np.array_equal(back, host1)
+        _lib.check(lib.pcx_spline_eval_multi_batch_dev(s.handle, d_pts, n, _lib.p_i32(_lib.i32(specs)), 3, d_out), lib)
+        backm = np.empty((n, 3))
+        _lib.check(lib.pcx_memcpy_d2h(0, backm.ctypes.data_as(ctypes.c_void_p), d_out, backm.nbytes), lib)
+        assert np.array_equal(backm, hostm)
+        lib.pcx_dev_free(0, d_pts)
+        lib.pcx_dev_free(0, d_out)
+    assert lib.pcx_spline_eval_batch_dev(s.handle, None, 5, None, None) < 0
+    assert lib.pcx_spline_eval_batch_dev(s.handle, None, 0, None, None) == 0
+
+
+@pytest.mark.gpu
+def test_spline_routing_without_lds_histograms(monkeypatch):
+    """Splines with more than 4,096 pieces bucket with wave-grouped global atomics; the same path forced on
+    a small spline gives the same values."""
+    case = F.SPLINE_CASES["c"]
+    sp = _build(case)
+    pts = golden("g9_splines")["c_points"]
+    want = sp.eval_multi_batch(pts, case["specs"])
+    monkeypatch.setenv("PCX_SPLINE_GLOBAL_HIST", "1")
+    sp.to_device(0)                                        # new handle, created under the override
+    assert np.array_equal(sp.eval_multi_batch(pts, case["specs"]), want)
+    big = np.tile(pts, (40, 1))
+    assert np.array_equal(sp.eval_batch(big, case["specs"][0]), np.tile(want[:, 0], 40))
