@@ -1140,6 +1140,11 @@ struct pcx_spline {
     double *d_knots = nullptr;
     int *d_counts = nullptr;             // n_pieces: histogram, then bucket cursors
     int lds_hist = 1;                    // routing kernels count per workgroup in LDS (<= PCX_SPLINE_LDS_PIECES pieces)
+    // the per-piece launches of one batch are independent: they go round-robin over a few side streams so
+    // that small buckets overlap instead of queueing behind each other's launch latency
+    static const int kSide = 4;
+    hipStream_t side[kSide] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
     Scratch s_pts, s_out, s_piece, s_perm, s_partial;
 };
@@ -1151,6 +1156,11 @@ extern "C" int pcx_spline_destroy(pcx_spline *h) {
     (void)hipFree(h->d_knots);
     (void)hipFree(h->d_counts);
     h->s_pts.release(); h->s_out.release(); h->s_piece.release(); h->s_perm.release(); h->s_partial.release();
+    for (int i = 0; i < pcx_spline::kSide; ++i) {
+        if (h->side[i]) { (void)hipStreamSynchronize(h->side[i]); (void)hipStreamDestroy(h->side[i]); }
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PCX_OK;
@@ -1193,6 +1203,13 @@ extern "C" int pcx_spline_create(int device, int d, const int32_t *n_knots, cons
         h->lds_hist = (n_pieces <= PCX_SPLINE_LDS_PIECES && !(g && g[0] == '1')) ? 1 : 0;
     }
     hipError_t e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+    if (n_pieces > 2) {
+        for (int i = 0; i < pcx_spline::kSide && e == hipSuccess; ++i) {
+            e = hipStreamCreateWithFlags(&h->side[i], hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming);
+        }
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming);
+    }
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_knots, (nk_total ? nk_total : 1) * sizeof(double));
     if (e == hipSuccess && nk_total) e = hipMemcpy(h->d_knots, knots_cat, nk_total * sizeof(double), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&h->d_counts, (size_t)n_pieces * sizeof(int));
@@ -1237,6 +1254,17 @@ static int spline_eval_chunk(pcx_spline *h, const double *dp, long cnt, const in
     int rc = spline_bucket(h, dp, cnt, counts, offsets);
     if (rc) return rc;
     const int *perm = (const int *)h->s_perm.ptr;
+    int busy = 0;
+    for (int i = 0; i < h->n_pieces; ++i) busy += counts[i] ? 1 : 0;
+    // fork: with several small buckets the launches go round-robin over the side streams (each waits for the
+    // bucketing on h->stream); join: h->stream waits for every side stream used.  The row kernel's split
+    // scratch is per handle, so only the main stream may use it: side launches pass nullptr (no split).
+    const bool fan = h->ev_fork && busy > 2 && cnt / busy < (1 << 18);
+    if (fan) {
+        HIP_TRY(hipEventRecord(h->ev_fork, h->stream));
+        for (int i = 0; i < pcx_spline::kSide; ++i) HIP_TRY(hipStreamWaitEvent(h->side[i], h->ev_fork, 0));
+    }
+    int turn = 0;
     for (int i = 0; i < h->n_pieces; ++i) {
         if (counts[i] == 0) continue;
         pcx_bary *pc = h->pieces[i];
@@ -1253,16 +1281,23 @@ static int spline_eval_chunk(pcx_spline *h, const double *dp, long cnt, const in
             std::vector<double *> tab(m);
             for (int s = 0; s < m; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
             if (tab != pc->tab_host) {
-                HIP_TRY(hipStreamSynchronize(h->stream));   // earlier launches may still read d_tab
+                HIP_TRY(hipDeviceSynchronize());            // earlier launches (any stream) may still read d_tab
                 HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
                 pc->tab_host = tab;
             }
             frag_tab = pc->d_tab;
         }
-        rc = bary_launch(pc, dts.data(), m, frag_tab, dp, counts[i], dout, m, 0, h->stream, &h->s_partial,
+        hipStream_t st = fan ? h->side[turn % pcx_spline::kSide] : h->stream;
+        ++turn;
+        rc = bary_launch(pc, dts.data(), m, frag_tab, dp, counts[i], dout, m, 0, st, fan ? nullptr : &h->s_partial,
                          perm + offsets[i]);
         if (rc) return rc;
     }
+    if (fan)
+        for (int i = 0; i < pcx_spline::kSide && i < turn; ++i) {
+            HIP_TRY(hipEventRecord(h->ev_join[i], h->side[i]));
+            HIP_TRY(hipStreamWaitEvent(h->stream, h->ev_join[i], 0));
+        }
     return PCX_OK;
 }
 
