@@ -59,6 +59,10 @@ int pcx_device_info(int device, char *name, int name_len, int *compute_units, in
  * (bench.py, multi-GPU drivers).  `stream` arguments are hipStream_t passed as void*. */
 int pcx_dev_malloc(int device, size_t bytes, void **dptr);
 int pcx_dev_free(int device, void *dptr);
+/* The device a pointer lives on (hipPointerGetAttributes); PCX_ERR_INVALID for host or
+ * unknown memory.  Lets a host that received a device array from another library
+ * (`__cuda_array_interface__`) check it before handing it to a `_dev` entry point.    */
+int pcx_pointer_device(const void *ptr, int *device);
 int pcx_memcpy_h2d(int device, void *dst, const void *src, size_t bytes);
 int pcx_memcpy_d2h(int device, void *dst, const void *src, size_t bytes);
 int pcx_device_synchronize(int device);
@@ -116,6 +120,10 @@ int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t N, const i
  * specs (m x d orders) at each of N points; out is (N, m) row-major.                  */
 int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs,
                               int m, double *out);
+/* Device-resident form: d_pts (N x d) and d_out (N x m) in HBM; enqueues on `stream`
+ * (NULL = the handle's own) and returns without synchronizing.                         */
+int pcx_bary_eval_multi_batch_dev(pcx_bary *h, const double *d_pts, int64_t N,
+                                  const int32_t *derivs, int m, double *d_out, void *stream);
 
 /* The derivative-transformed tensor of _apply_derivative_passes (:951-990), copied to
  * the host (prod n_d doubles) -- lets tests check kernel K3 on its own.               */

@@ -36,9 +36,10 @@ class SpecialPoints:
 
 
 from .barycentric import ChebyshevApproximation  # noqa: E402
+from .device import DeviceArray  # noqa: E402
 from .slider import ChebyshevSlider  # noqa: E402
 from .spline import ChebyshevSpline  # noqa: E402
 from .tensor_train import ChebyshevTT  # noqa: E402
 
-__all__ = ["ChebyshevApproximation", "ChebyshevSlider", "ChebyshevSpline", "ChebyshevTT", "Domain", "Ns",
+__all__ = ["ChebyshevApproximation", "ChebyshevSlider", "ChebyshevSpline", "ChebyshevTT", "DeviceArray", "Domain", "Ns",
            "SpecialPoints", "__version__"]

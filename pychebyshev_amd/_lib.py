@@ -52,6 +52,7 @@ SIGNATURES = {
     "pcx_device_info": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(_I), c_i64p]),
     "pcx_dev_malloc": (_I, [_I, _Z, c_vpp]),
     "pcx_dev_free": (_I, [_I, _V]),
+    "pcx_pointer_device": (_I, [_V, ctypes.POINTER(_I)]),
     "pcx_memcpy_h2d": (_I, [_I, _V, _V, _Z]),
     "pcx_memcpy_d2h": (_I, [_I, _V, _V, _Z]),
     "pcx_device_synchronize": (_I, [_I]),
@@ -75,6 +76,7 @@ SIGNATURES = {
     "pcx_bary_eval_batch": (_I, [_V, c_f64p, _L, c_i32p, c_f64p]),
     "pcx_bary_eval_batch_dev": (_I, [_V, _V, _L, c_i32p, _V, _V]),
     "pcx_bary_eval_multi_batch": (_I, [_V, c_f64p, _L, c_i32p, _I, c_f64p]),
+    "pcx_bary_eval_multi_batch_dev": (_I, [_V, _V, _L, c_i32p, _I, _V, _V]),
     "pcx_bary_derivative_tensor": (_I, [_V, c_i32p, c_f64p]),
     "pcx_tensor_contract_axis": (_I, [_I, _I, c_i32p, c_f64p, _I, c_f64p, c_f64p]),
     "pcx_bary_set_kernel": (_I, [_V, _I]),

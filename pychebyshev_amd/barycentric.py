@@ -438,7 +438,27 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
             raise ValueError(f"derivative_order must have {self.num_dimensions} entries, got {list(np.shape(orders))}")
         return _lib.i32(arr)
 
+    def _eval_points_dev(self, dev_pts, specs: np.ndarray, flat: bool):
+        """Device-resident batch (see :mod:`pychebyshev_amd.device`): ``specs`` is ``(m, d)`` int32;
+        returns a ``DeviceArray`` of shape ``(N,)`` (``flat``, m = 1) or ``(N, m)``; complete on return."""
+        from .device import DeviceArray, check_points
+        m = self._model()
+        n = check_points(dev_pts, self.num_dimensions, m.device)
+        k = specs.shape[0]
+        out = DeviceArray.empty((n,) if flat else (n, k), m.device)
+        if n:
+            st = ctypes.c_void_p()
+            _lib.check(m.lib.pcx_bary_stream(m.handle, ctypes.byref(st)), m.lib)
+            _lib.check(m.lib.pcx_bary_eval_multi_batch_dev(m.handle, ctypes.c_void_p(dev_pts.ptr), n, _lib.p_i32(specs), k,
+                                                           ctypes.c_void_p(out.ptr), st), m.lib)
+            _lib.check(m.lib.pcx_stream_synchronize(st), m.lib)
+        return out
+
     def _eval_points(self, pts: np.ndarray, orders) -> np.ndarray:
+        from .device import as_device_array
+        dev_pts = as_device_array(pts)
+        if dev_pts is not None:
+            return self._eval_points_dev(dev_pts, self._check_orders(orders).reshape(1, -1), True)
         m = self._model()
         pts = _lib.f64(pts)
         if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
@@ -492,11 +512,15 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         (Extension: the reference has no batched form; price + Greeks in one call.)"""
         if self.tensor_values is None:
             raise RuntimeError("Call build() first")
+        specs = _lib.i32(np.asarray(derivative_orders).reshape(-1, self.num_dimensions))
+        from .device import as_device_array
+        dev_pts = as_device_array(points)
+        if dev_pts is not None:
+            return self._eval_points_dev(dev_pts, specs, False)
         m = self._model()
         pts = _lib.f64(points)
         if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
             raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
-        specs = _lib.i32(np.asarray(derivative_orders).reshape(-1, self.num_dimensions))
         out = np.empty((pts.shape[0], specs.shape[0]))
         _lib.check(m.lib.pcx_bary_eval_multi_batch(m.handle, _lib.p_f64(pts), pts.shape[0],
                                                    _lib.p_i32(specs), specs.shape[0],
@@ -505,10 +529,16 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
 
     # aliases for the words BASELINE.json uses; the reference names above stay primary
     def evaluate(self, points, derivative_order=None) -> np.ndarray:
+        from .device import is_device_array
         order = [0] * self.num_dimensions if derivative_order is None else derivative_order
+        if is_device_array(points):
+            return self.vectorized_eval_batch(points, order)
         return self.vectorized_eval_batch(np.atleast_2d(np.asarray(points, dtype=float)), order)
 
     def derivative(self, points, derivative_order) -> np.ndarray:
+        from .device import is_device_array
+        if is_device_array(points):
+            return self.vectorized_eval_batch(points, derivative_order)
         return self.vectorized_eval_batch(np.atleast_2d(np.asarray(points, dtype=float)), derivative_order)
 
     # ---------------------------------------------------------------- small getters

@@ -87,6 +87,16 @@ extern "C" int pcx_dev_malloc(int device, size_t bytes, void **dptr) {
     HIP_TRY(hipMalloc(dptr, bytes ? bytes : 8));
     return PCX_OK;
 }
+extern "C" int pcx_pointer_device(const void *ptr, int *device) {
+    if (!ptr || !device) return fail(PCX_ERR_INVALID, "NULL argument");
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, ptr);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(PCX_ERR_INVALID, "not a HIP pointer: %s", hipGetErrorString(e)); }
+    if (attr.type != hipMemoryTypeDevice) return fail(PCX_ERR_INVALID, "pointer is not device memory (memory type %d)", (int)attr.type);
+    *device = attr.device;
+    return PCX_OK;
+}
+
 extern "C" int pcx_dev_free(int device, void *dptr) {
     int rc = use_device(device);
     if (rc) return rc;
@@ -947,6 +957,45 @@ extern "C" int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t
     // split launches share the handle's scratch: only on the handle's own stream
     return bary_launch(h, &dt, 1, dt->slot, d_pts, (long)N, d_out, 1, 0, st,
                        st == h->stream ? &h->s_partial : nullptr);
+}
+
+// m specs at N device-resident points into d_out (N x m row-major); groups of kMaxSpecs specs per launch.
+extern "C" int pcx_bary_eval_multi_batch_dev(pcx_bary *h, const double *d_pts, int64_t N, const int32_t *derivs,
+                                             int m, double *d_out, void *stream) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (!derivs) return fail(PCX_ERR_INVALID, "derivs is NULL");
+    if (N == 0) return PCX_OK;
+    if (!d_pts || !d_out) return fail(PCX_ERR_INVALID, "NULL device buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->call_mark = h->clock;
+    const int d = h->dims.d;
+    hipStream_t st = stream ? (hipStream_t)stream : h->stream;
+    for (int s0 = 0; s0 < m; s0 += kMaxSpecs) {
+        const int mc = std::min(kMaxSpecs, m - s0);
+        std::vector<DerivedTensor *> dts(mc);
+        for (int s = 0; s < mc; ++s) {
+            int rc = bary_get_tensor(h, derivs + (size_t)(s0 + s) * d, &dts[s]);
+            if (rc) return rc;
+        }
+        const double *const *frag_tab = dts[0]->slot;
+        const int eff = bary_effective_variant(h);
+        if (mc > 1 && (eff == 4 || h->mfma_ok)) {
+            std::vector<double *> tab(mc);
+            for (int s = 0; s < mc; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
+            if (tab != h->tab_host) {
+                HIP_TRY(hipDeviceSynchronize());        // launches still in flight on any stream may read d_tab
+                HIP_TRY(hipMemcpy(h->d_tab, tab.data(), mc * sizeof(double *), hipMemcpyHostToDevice));
+                h->tab_host = tab;
+            }
+            frag_tab = h->d_tab;
+        }
+        int rc = bary_launch(h, dts.data(), mc, frag_tab, d_pts, (long)N, d_out, m, s0, st,
+                             st == h->stream ? &h->s_partial : nullptr);
+        if (rc) return rc;
+    }
+    return PCX_OK;
 }
 
 static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs, int m,

@@ -184,16 +184,30 @@ class ChebyshevSlider(ErgonomicsMixin, DerivativeIdMixin):
         if not self._built:
             raise RuntimeError("Call build() before eval_batch().")
         derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
-        return self.eval_multi_batch(points, [list(derivative_order)])[:, 0]
+        out = self.eval_multi_batch(points, [list(derivative_order)])
+        if isinstance(out, np.ndarray):
+            return out[:, 0]
+        out.shape = (out.shape[0],)           # (N, 1) device result: same memory as (N,)
+        return out
 
     def eval_multi_batch(self, points, derivative_orders) -> np.ndarray:
         """``(N, d)`` points x ``m`` specs -> ``(N, m)`` (extension); value specs share the slides' values."""
         if not self._built:
             raise RuntimeError("Call build() before eval_multi_batch().")
+        specs = _lib.i32(np.asarray(derivative_orders).reshape(-1, self.num_dimensions))
+        from .device import DeviceArray, as_device_array, check_points
+        dev_pts = as_device_array(points)
+        if dev_pts is not None:           # device-resident batch: the result stays in HBM
+            s = self._dev()
+            n = check_points(dev_pts, self.num_dimensions, s.device)
+            dout = DeviceArray.empty((n, specs.shape[0]), s.device)
+            if n:
+                _lib.check(s.lib.pcx_slider_eval_multi_batch_dev(s.handle, ctypes.c_void_p(dev_pts.ptr), n, _lib.p_i32(specs),
+                                                                 specs.shape[0], ctypes.c_void_p(dout.ptr)), s.lib)
+            return dout
         pts = _lib.f64(points)
         if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
             raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
-        specs = _lib.i32(np.asarray(derivative_orders).reshape(-1, self.num_dimensions))
         s = self._dev()
         out = np.empty((pts.shape[0], specs.shape[0]))
         _lib.check(s.lib.pcx_slider_eval_multi_batch(s.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_i32(specs),

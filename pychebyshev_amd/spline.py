@@ -375,10 +375,14 @@ class ChebyshevSpline(ErgonomicsMixin, DerivativeIdMixin):
         if not self._built:
             raise RuntimeError("Call build() before eval_batch().")
         derivative_order = self._resolve_derivative_args(derivative_order, derivative_id)
-        pts = self._points(np.asarray(points, dtype=float))
         spec = _lib.i32(derivative_order)
         if spec.shape != (self.num_dimensions,):
             raise ValueError(f"derivative_order must have {self.num_dimensions} entries")
+        from .device import as_device_array
+        dev_pts = as_device_array(points)
+        if dev_pts is not None:
+            return self._eval_dev(dev_pts, spec.reshape(1, -1), True)
+        pts = self._points(np.asarray(points, dtype=float))
         s = self._dev()
         out = np.empty(pts.shape[0])
         _lib.check(s.lib.pcx_spline_eval_batch(s.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_i32(spec),
@@ -389,13 +393,33 @@ class ChebyshevSpline(ErgonomicsMixin, DerivativeIdMixin):
         """Batched ``eval_multi``: ``(N, d)`` points x ``m`` specs -> ``(N, m)`` (extension)."""
         if not self._built:
             raise RuntimeError("Call build() before eval_multi_batch().")
-        pts = self._points(np.asarray(points, dtype=float))
         specs = _lib.i32(np.asarray(derivative_orders).reshape(-1, self.num_dimensions))
+        from .device import as_device_array
+        dev_pts = as_device_array(points)
+        if dev_pts is not None:
+            return self._eval_dev(dev_pts, specs, False)
+        pts = self._points(np.asarray(points, dtype=float))
         s = self._dev()
         out = np.empty((pts.shape[0], specs.shape[0]))
         _lib.check(s.lib.pcx_spline_eval_multi_batch(s.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_i32(specs),
                                                      specs.shape[0], _lib.p_f64(out)), s.lib)
         return out
+
+    def _eval_dev(self, dev_pts, specs: np.ndarray, flat: bool):
+        """Device-resident batch (:mod:`pychebyshev_amd.device`): ``(N,)`` / ``(N, m)`` ``DeviceArray``;
+        specs go in groups of 64 (one ``pcx_spline_eval_multi_batch_dev`` call each)."""
+        from .device import DeviceArray, check_points
+        s = self._dev()
+        n = check_points(dev_pts, self.num_dimensions, s.device)
+        m = specs.shape[0]
+        out = DeviceArray.empty((n,) if flat else (n, m), s.device)
+        if n == 0:
+            return out
+        if m <= 64:
+            _lib.check(s.lib.pcx_spline_eval_multi_batch_dev(s.handle, ctypes.c_void_p(dev_pts.ptr), n, _lib.p_i32(specs), m,
+                                                             ctypes.c_void_p(out.ptr)), s.lib)
+            return out
+        raise ValueError("device-resident spline batches take at most 64 derivative specs per call")
 
     def piece_indices(self, points) -> np.ndarray:
         """Flat piece index of every point, computed on the device (diagnostic)."""

@@ -498,6 +498,17 @@ class ChebyshevTT(ErgonomicsMixin):
     def _eval_user_points(self, pts: np.ndarray) -> np.ndarray:
         """Points in the USER's dimension order; the device applies ``_dim_order``."""
         t = self._dev()
+        from .device import DeviceArray, as_device_array, check_points
+        dev_pts = as_device_array(pts)
+        if dev_pts is not None:       # device-resident batch: result stays in HBM, complete on return
+            n = check_points(dev_pts, self.num_dimensions, t.device)
+            dout = DeviceArray.empty((n,), t.device)
+            if n:
+                st = ctypes.c_void_p()
+                _lib.check(t.lib.pcx_tt_stream(t.handle, ctypes.byref(st)), t.lib)
+                _lib.check(t.lib.pcx_tt_eval_batch_dev(t.handle, ctypes.c_void_p(dev_pts.ptr), n, ctypes.c_void_p(dout.ptr), st), t.lib)
+                _lib.check(t.lib.pcx_stream_synchronize(st), t.lib)
+            return dout
         pts = _lib.f64(pts)
         if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
             raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
@@ -522,7 +533,8 @@ class ChebyshevTT(ErgonomicsMixin):
     def eval_batch(self, points) -> np.ndarray:
         """Values at ``(N, num_dimensions)`` points (reference :2217-2265)."""
         self._check_built()
-        return self._eval_user_points(np.asarray(points))
+        from .device import is_device_array
+        return self._eval_user_points(points if is_device_array(points) else np.asarray(points))
 
     def eval_multi(self, point, derivative_orders) -> List[float]:
         """Value and central-finite-difference derivatives at one point (reference
