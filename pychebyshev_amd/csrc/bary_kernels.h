@@ -622,16 +622,25 @@ k_bary_rows(BaryDims dims, int LPP, const double *__restrict__ nodes,
 // one-hot row exactly (every other product contains the factor 0; b_j = c_j / c_j = 1); within
 // 1e-14 of a node, where the reference switches to the node's value, this evaluates the
 // interpolant at x itself -- the two differ by O(1e-14), far inside the 1e-12 bar.
-template <int NLP>
-__device__ __forceinline__ void bary_weights_reg(double x, double scale, const double *__restrict__ snodes,
-                                                 const double *__restrict__ wts, int n, double (&b)[NLP]) {
+// Model data the evaluation kernels only read (tensor, scaled nodes, weights) goes through a
+// CONSTANT-address-space pointer: with a wave-uniform address that is what lets hipcc use scalar loads
+// (s_load into SGPRs) whatever it can or cannot prove about aliasing with `out` -- a plain `const double *`
+// fell back to 64-lane vector loads of the same address, one exposed memory round trip per node.
+typedef const double __attribute__((address_space(4))) *pcx_cptr;
+__device__ __forceinline__ pcx_cptr pcx_as_constant(const double *p) { return (pcx_cptr)(unsigned long long)p; }
+
+// EXACT: the dimension has exactly NLP nodes -- no per-node `j < n` tests (hipcc turns those into six
+// v_cndmask per node in the suffix pass and a branch + dependent load per node in the prefix pass).
+template <int NLP, bool EXACT>
+__device__ __forceinline__ void bary_weights_reg(double x, double scale, pcx_cptr snodes, pcx_cptr wts, int n,
+                                                 double (&b)[NLP]) {
     double t[NLP];
     double run = 1.0;
 #pragma unroll
     for (int j = 0; j < NLP; ++j) {                 // b_j <- w_j * prefix_j
         b[j] = 0.0;
         t[j] = 1.0;
-        if (j < n) {
+        if (EXACT || j < n) {
             t[j] = __builtin_fma(x, scale, -snodes[j]);
             b[j] = wts[j] * run;
             run *= t[j];
@@ -641,7 +650,7 @@ __device__ __forceinline__ void bary_weights_reg(double x, double scale, const d
     double su = 0.0;
 #pragma unroll
     for (int j = NLP - 1; j >= 0; --j) {            // b_j <- b_j * suffix_j
-        if (j < n) {
+        if (EXACT || j < n) {
             b[j] *= run;
             su += b[j];
             run *= t[j];
@@ -653,8 +662,8 @@ __device__ __forceinline__ void bary_weights_reg(double x, double scale, const d
 }
 
 // The same through a lane's column of an LDS table (runtime node count): dst[j * stride].
-__device__ __forceinline__ void bary_weights_prod(double x, double scale, const double *__restrict__ snodes,
-                                                  const double *__restrict__ wts, int n, double *dst, int stride) {
+__device__ __forceinline__ void bary_weights_prod(double x, double scale, pcx_cptr snodes, pcx_cptr wts, int n,
+                                                  double *dst, int stride) {
     double run = 1.0;
     for (int j = 0; j < n; ++j) {
         dst[j * stride] = wts[j] * run;
@@ -671,13 +680,6 @@ __device__ __forceinline__ void bary_weights_prod(double x, double scale, const 
     const double r = 1.0 / su;
     for (int j = 0; j < n; ++j) dst[j * stride] *= r;
 }
-
-// The tensor is read through a CONSTANT-address-space pointer: it is never written while an evaluation
-// kernel runs, and with a wave-uniform address that is what lets hipcc use scalar loads (s_load into
-// SGPRs) whatever it can or cannot prove about aliasing with `out` (a tensor pointer fetched from a
-// multi-spec table carries no noalias information and fell back to 64-lane flat loads).
-typedef const double __attribute__((address_space(4))) *pcx_cptr;
-__device__ __forceinline__ pcx_cptr pcx_as_constant(const double *p) { return (pcx_cptr)(unsigned long long)p; }
 
 template <int LEVEL, int DOUT, int NLP>
 __device__ __forceinline__ double bary_small_nest(const BaryDims &dims, pcx_cptr Tb,
@@ -717,16 +719,20 @@ k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes
     const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
     const int d = DOUT + 1;
     double *bw_lane = lds + lane;
+    const pcx_cptr csn = pcx_as_constant(snodes), cw = pcx_as_constant(wts), cnd = pcx_as_constant(nodes);
 #pragma unroll
     for (int k = 0; k < DOUT; ++k) {
-        const double x = valid ? pts[row * d + k] : nodes[dims.off[k]];
-        bary_weights_prod(x, sc.s[k], snodes + dims.off[k], wts + dims.off[k], dims.n[k],
+        const double x = valid ? pts[row * d + k] : cnd[dims.off[k]];
+        bary_weights_prod(x, sc.s[k], csn + dims.off[k], cw + dims.off[k], dims.n[k],
                           bw_lane + (size_t)dims.off[k] * 64, 64);
     }
     double bl[NLP];
     {
-        const double x = valid ? pts[row * d + DOUT] : nodes[dims.off[DOUT]];
-        bary_weights_reg<NLP>(x, sc.s[DOUT], snodes + dims.off[DOUT], wts + dims.off[DOUT], dims.n[DOUT], bl);
+        const double x = valid ? pts[row * d + DOUT] : cnd[dims.off[DOUT]];
+        if (dims.n[DOUT] == NLP)     // wave-uniform
+            bary_weights_reg<NLP, true>(x, sc.s[DOUT], csn + dims.off[DOUT], cw + dims.off[DOUT], NLP, bl);
+        else
+            bary_weights_reg<NLP, false>(x, sc.s[DOUT], csn + dims.off[DOUT], cw + dims.off[DOUT], dims.n[DOUT], bl);
     }
     // the table is wave-private (one wave per workgroup): no barrier
     if (T_tab == nullptr) {

@@ -486,7 +486,8 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     // tensor is small enough that the MFMA kernel's prologue outweighs its tiles
     // (tools/bary_rate_probe.py, profiles/r02_bary_rate_probe.txt).
     {
-        static const int kNlp[] = {4, 8, 12, 16, 24, 32, 48, 64};
+        // every node count up to 16 has its own instantiation (no padding, no per-node tests); classes above
+        static const int kNlp[] = {2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 24, 32, 48, 64};
         const int nl = h->dims.n[d - 1];
         const long outer_rows = sum_n - nl;
         if (d <= 4 && nl <= 64 && outer_rows * 64 * (long)sizeof(double) <= 64 * 1024 && total <= (1L << 22)) {
@@ -884,7 +885,8 @@ static int launch_small_d(pcx_bary *h, const DerivedTensor &dt, const double *co
                           long N, double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
     switch (h->small_nlp) {
 #define CASE_NLP(v) case v: return launch_small_t<DOUT, v>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
-    CASE_NLP(4) CASE_NLP(8) CASE_NLP(12) CASE_NLP(16) CASE_NLP(24) CASE_NLP(32) CASE_NLP(48) CASE_NLP(64)
+    CASE_NLP(2) CASE_NLP(3) CASE_NLP(4) CASE_NLP(5) CASE_NLP(6) CASE_NLP(7) CASE_NLP(8) CASE_NLP(9) CASE_NLP(10) CASE_NLP(11)
+    CASE_NLP(12) CASE_NLP(13) CASE_NLP(14) CASE_NLP(15) CASE_NLP(16) CASE_NLP(24) CASE_NLP(32) CASE_NLP(48) CASE_NLP(64)
 #undef CASE_NLP
     }
     return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
