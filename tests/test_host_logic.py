@@ -344,3 +344,35 @@ def test_accessor_surface_of_all_four_classes():
     pts = sl.get_evaluation_points()
     assert pts.shape == (23, 3) and np.all(pts[:20, 1] == 0.2) and np.all(pts[20:, 0] == 0.1) and np.all(pts[20:, 2] == 0.3)
     assert sl.clone().pivot_point == [0.1, 0.2, 0.3] and sl.clone().function is None
+
+
+def test_device_array_protocol_helpers_without_a_gpu():
+    """The `__cuda_array_interface__` plumbing that needs no device: what counts as a device array, the
+    C-contiguity rule, the dtype rule (pychebyshev_amd/device.py)."""
+    from pychebyshev_amd.device import DeviceArray, _c_contiguous, as_device_array, check_points, is_device_array
+    assert not is_device_array(np.zeros(3)) and not is_device_array([1.0, 2.0])
+    assert as_device_array(np.zeros((2, 2))) is None and as_device_array([[1.0]]) is None
+    assert _c_contiguous((5, 3), None) and _c_contiguous((5, 3), (24, 8)) and _c_contiguous((1, 3), (999, 8))
+    assert not _c_contiguous((5, 3), (8, 40)) and not _c_contiguous((5, 3), (48, 16))
+
+    class Fake:
+        def __init__(self, typestr="<f8", strides=None):
+            self.__cuda_array_interface__ = {"shape": (0, 3), "typestr": typestr, "data": (0, False), "version": 3,
+                                             "strides": strides}
+
+    assert is_device_array(Fake())
+    empty = as_device_array(Fake())                       # an empty batch never reaches the library
+    assert isinstance(empty, DeviceArray) and empty.shape == (0, 3) and empty.size == 0 and not empty._owns
+    assert check_points(empty, 3, 0) == 0
+    with pytest.raises(ValueError, match="shape"):
+        check_points(empty, 5, 0)
+    with pytest.raises(TypeError, match="float64"):
+        as_device_array(Fake("<f4"))
+    with pytest.raises(TypeError, match="float64"):
+        as_device_array(Fake("<i8"))
+    d = DeviceArray(1234, (7, 2), 1, owns=False)
+    assert d.nbytes == 112 and d.ndim == 2 and d.__cuda_array_interface__["data"] == (1234, False)
+    assert "borrowed" in repr(d)
+    other = DeviceArray(1234, (7, 2), 1, owns=False)
+    with pytest.raises(ValueError, match="device 1"):
+        check_points(other, 2, 0)
