@@ -156,3 +156,50 @@ def test_torch_tensors_in_and_out():
     """)
     res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert res.returncode == 0 and "torch-interop-ok" in res.stdout, res.stdout[-2000:] + res.stderr[-4000:]
+
+
+def test_handles_are_safe_under_concurrent_host_threads():
+    """evaluation is re-entrant.  ctypes drops the GIL inside the library, so four Python
+    threads really are inside libpcx_hip at once: same barycentric handle with different derivative specs
+    (cache fills + evictions under the handle mutex), a TT handle, a spline and a slider -- every result
+    equals the single-threaded one bit for bit."""
+    import threading
+    g = golden("g2_bs5d")
+    cheb = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, [11] * 5)
+    g4 = golden("g4_tt_bs5d")
+    tt = ChebyshevTT.from_coeff_cores([g4[f"r8_core{k}"] for k in range(5)], F.BS5_DOMAIN)
+    case = F.SPLINE_CASES["c"]
+    sp = ChebyshevSpline(getattr(F, case["f"]), case["d"], case["domain"], case["n_nodes"], knots=case["knots"])
+    sp.build(verbose=False)
+    sc = F.SLIDER_CASES["b"]
+    sl = ChebyshevSlider(getattr(F, sc["f"]), sc["d"], sc["domain"], sc["n_nodes"], partition=sc["partition"],
+                         pivot_point=sc["pivot"])
+    sl.build(verbose=False)
+    rng = np.random.default_rng(11)
+    pts = np.column_stack([rng.uniform(lo, hi, 30_000) for lo, hi in F.BS5_DOMAIN])
+    p3 = np.column_stack([rng.uniform(lo, hi, 30_000) for lo, hi in case["domain"]])
+    specs = [[0] * 5, [1, 0, 0, 0, 0], [0, 0, 0, 1, 0], [2, 0, 0, 0, 0], [1, 0, 0, 1, 0], [0, 0, 1, 0, 0]]
+    jobs = [(lambda s=s: cheb.vectorized_eval_batch(pts, s)) for s in specs]
+    jobs += [lambda: tt.eval_batch(pts), lambda: sp.eval_batch(p3, case["specs"][1]),
+             lambda: sl.eval_batch(pts, [0] * 5), lambda: cheb.vectorized_eval_multi_batch(pts[:5000], specs)]
+    want = [job() for job in jobs]
+    got = [[None] * len(jobs) for _ in range(3)]
+    errors = []
+
+    def worker(t, order):
+        try:
+            for i in order:
+                got[t][i] = jobs[i]()
+        except Exception as exc:                      # noqa: BLE001
+            errors.append(repr(exc))
+
+    threads = [threading.Thread(target=worker, args=(t, list(np.random.default_rng(t).permutation(len(jobs)))))
+               for t in range(3)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+    for t in range(3):
+        for i in range(len(jobs)):
+            assert np.array_equal(got[t][i], want[i]), (t, i)
