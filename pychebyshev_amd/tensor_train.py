@@ -565,6 +565,45 @@ class ChebyshevTT(ErgonomicsMixin):
         it = iter(vals)
         return run(lambda p: float(next(it)))         # pass 2: same traversal, real values
 
+    def eval_multi_batch(self, points, derivative_orders, *, chunk: int = 1 << 18) -> np.ndarray:
+        """Batched :meth:`eval_multi` (extension; the reference evaluates one point per call): ``(N, d)``
+        points x ``m`` specs -> ``(N, m)``.  The finite-difference rules run on whole columns -- the same
+        record / replay traversal as :meth:`eval_multi` with NumPy columns in place of floats, so row i
+        equals ``eval_multi(points[i], derivative_orders)`` bit for bit -- and all stencil points of a
+        chunk of rows go to the device in one batch."""
+        self._check_built()
+        d = self.num_dimensions
+        pts = np.asarray(points, dtype=float)
+        if pts.ndim != 2 or pts.shape[1] != d:
+            raise ValueError(f"points must have shape (N, {d}), got {pts.shape}")
+        order = self._dim_order
+        specs = [[int(s[order[k]]) for k in range(d)] for s in derivative_orders]
+        for spec in specs:
+            for o in spec:
+                if o not in (0, 1, 2):
+                    raise ValueError(f"Derivative order {o} not supported (use 1 or 2)")
+        out = np.empty((pts.shape[0], len(specs)))
+        for start in range(0, pts.shape[0], max(1, int(chunk))):
+            block = pts[start:start + chunk]
+            n = block.shape[0]
+            cols = [np.ascontiguousarray(block[:, order[k]]) for k in range(d)]       # storage frame
+            pending: list = []
+
+            def run(value_of):
+                return [self._fd_spec(cols, spec, value_of) for spec in specs]
+
+            def record(q):
+                pending.append(np.column_stack([np.broadcast_to(c, (n,)) for c in q]))
+                return 0.0
+
+            run(record)                               # pass 1: collect the stencil columns
+            vals = self._eval_user_points(self._storage_to_user(np.concatenate(pending, axis=0)))
+            it = iter(np.split(vals, len(pending)))
+            res = run(lambda q: next(it))             # pass 2: same traversal, real values
+            for j, r in enumerate(res):
+                out[start:start + n, j] = r
+        return out
+
     def to_dense(self) -> np.ndarray:
         """Full tensor of values on the Chebyshev grid, axes in the user's dimension order
         (reference :1874-1917).  One device batch over all ``prod(n_nodes)`` grid points
@@ -590,9 +629,14 @@ class ChebyshevTT(ErgonomicsMixin):
         return (b - a) * 1e-4
 
     def _nudge(self, p, k: int, h: float):
+        """``p`` is a point (list of floats) or, for the batched rules, a list of ``(N,)`` columns."""
         p = list(p)
         a, b = self.domain[k]
         need = h * 1.5
+        if isinstance(p[k], np.ndarray):
+            x = np.where(p[k] - a < need, a + need, p[k])
+            p[k] = np.where(b - x < need, b - need, x)
+            return p
         if p[k] - a < need:
             p[k] = a + need
         if b - p[k] < need:
@@ -602,7 +646,7 @@ class ChebyshevTT(ErgonomicsMixin):
     @staticmethod
     def _moved(p, k, delta):
         q = list(p)
-        q[k] += delta
+        q[k] = q[k] + delta
         return q
 
     def _fd_nested(self, p, active, value_of):
@@ -631,8 +675,8 @@ class ChebyshevTT(ErgonomicsMixin):
 
             def at(s1, s2):
                 q = list(p)
-                q[k1] += s1 * h1
-                q[k2] += s2 * h2
+                q[k1] = q[k1] + s1 * h1               # not +=: the batched rules pass NumPy columns
+                q[k2] = q[k2] + s2 * h2
                 return value_of(q)
             f_pp, f_pm, f_mp, f_mm = at(+1, +1), at(+1, -1), at(-1, +1), at(-1, -1)
             return (f_pp - f_pm - f_mp + f_mm) / (4.0 * h1 * h2)

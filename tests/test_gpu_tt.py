@@ -440,3 +440,40 @@ def test_svd_and_cross_builds_agree_and_hit_the_closed_form():
     one_by_one = np.array([svd.eval(list(p)) for p in pts[:50]])
     assert np.max(np.abs(one_by_one - svd.eval_batch(pts[:50]))) <= 1e-12
     assert abs(svd.eval([0.1, 0.2, 0.3]) - (math.sin(0.1) + math.sin(0.2) + math.sin(0.3))) < 1e-8
+
+
+def test_eval_multi_batch_equals_eval_multi_row_by_row():
+    """The batched finite-difference Greeks (extension): every row equals eval_multi at that point bit for
+    bit -- interior points, points inside the 1.5 h boundary band (nudged), a permuted dim_order, the
+    4-point mixed rule, second order, nested rules; chunking does not change anything."""
+    g = golden("g4_tt_bs5d")
+    tt = ChebyshevTT.from_coeff_cores(_cores(g, "r8_", 5), F.BS5_DOMAIN)
+    rng = np.random.default_rng(21)
+    pts = np.column_stack([rng.uniform(lo, hi, 300) for lo, hi in F.BS5_DOMAIN])
+    for k, (lo, hi) in enumerate(F.BS5_DOMAIN):          # rows in the boundary band of each dimension
+        pts[2 * k, k] = lo + (hi - lo) * 1e-5
+        pts[2 * k + 1, k] = hi
+    specs = [[0] * 5, [1, 0, 0, 0, 0], [2, 0, 0, 0, 0], [0, 0, 0, 1, 0], [1, 0, 0, 1, 0], [1, 2, 0, 0, 0], [0, 0, 1, 0, 2]]
+    got = tt.eval_multi_batch(pts, specs)
+    assert got.shape == (300, len(specs))
+    for i in list(range(12)) + [50, 123, 299]:
+        assert np.array_equal(got[i], tt.eval_multi(list(pts[i]), specs)), i
+    assert np.array_equal(tt.eval_multi_batch(pts, specs, chunk=64), got)
+    assert np.array_equal(got[:, 0], tt.eval_batch(pts))
+    fd = np.array([tt.eval_multi(list(s), g["fd_specs"].tolist()) for s in g["scenarios"]])
+    assert np.array_equal(tt.eval_multi_batch(g["scenarios"], g["fd_specs"].tolist()), fd)
+    with pytest.raises(ValueError, match="not supported"):
+        tt.eval_multi_batch(pts, [[3, 0, 0, 0, 0]])
+    with pytest.raises(ValueError, match="shape"):
+        tt.eval_multi_batch(pts[:, :4], specs)
+    assert tt.eval_multi_batch(np.empty((0, 5)), specs).shape == (0, len(specs))
+    # permuted storage order
+    g5 = golden("g5_tt_rank16")
+    perm = [int(v) for v in g5["perm"]]
+    ttp = ChebyshevTT.from_coeff_cores(_cores(g5, "", 10), [[-1.0, 1.0]] * 10, dim_order=perm)
+    p10 = g5["points"][:40].copy()
+    p10[0, 3] = 1.0
+    s10 = [[0] * 10, [0, 1] + [0] * 8, [0] * 9 + [2], [1, 0, 0, 1] + [0] * 6]
+    gb = ttp.eval_multi_batch(p10, s10)
+    for i in (0, 1, 17, 39):
+        assert np.array_equal(gb[i], ttp.eval_multi(list(p10[i]), s10)), i

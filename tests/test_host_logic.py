@@ -258,6 +258,35 @@ def test_tt_fd_rules_replay_on_host():
         tt.eval_multi([0.3, 1.1], [[3, 0]])
 
 
+def test_tt_batched_fd_rules_equal_the_per_point_rules():
+    """eval_multi_batch runs the same rules on NumPy columns: row i = eval_multi(points[i]) bit for bit, with
+    nudged boundary rows, the 4-point mixed rule and a permuted storage order (stand-in evaluator, no device)."""
+    cores = [np.ones((1, 4, 1)), np.ones((1, 3, 1)), np.ones((1, 5, 1))]
+    dom = [[0.0, 1.0], [0.0, 2.0], [-1.0, 3.0]]
+    f = lambda p: np.sin(p[:, 0] * 3) * p[:, 1] * p[:, 2] + p[:, 0] ** 2 * np.exp(0.3 * p[:, 1]) + p[:, 2] ** 3
+    for order in (None, [2, 0, 1]):
+        tt = ChebyshevTT.from_coeff_cores(cores if order is None else [cores[2], cores[0], cores[1]],
+                                          dom, dim_order=order)
+        calls = []
+
+        def fake(pts):
+            calls.append(len(pts))
+            return f(np.asarray(pts, dtype=float))
+        tt._eval_user_points = fake
+        rng = np.random.default_rng(5)
+        pts = np.column_stack([rng.uniform(lo, hi, 40) for lo, hi in dom])
+        pts[0] = [0.0, 2.0, -1.0]
+        pts[1, 2] = 3.0 - 1e-6
+        specs = [[0, 0, 0], [1, 0, 0], [0, 2, 0], [1, 0, 1], [0, 1, 1], [1, 2, 0], [2, 0, 2]]
+        got = tt.eval_multi_batch(pts, specs)
+        assert calls == [40 * (1 + 2 + 3 + 4 + 4 + 6 + 9)]            # one device batch for the whole block
+        for i in range(40):
+            assert np.array_equal(got[i], tt.eval_multi(list(pts[i]), specs)), (order, i)
+        assert np.array_equal(tt.eval_multi_batch(pts, specs, chunk=9), got)
+        with pytest.raises(ValueError, match="not supported"):
+            tt.eval_multi_batch(pts, [[0, 3, 0]])
+
+
 def test_shard_bounds_cover_everything_once():
     for n in (0, 1, 7, 8, 1_000_003):
         for g in (1, 2, 3, 8):
