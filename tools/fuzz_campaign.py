@@ -1,0 +1,155 @@
+#!/usr/bin/env python3
+"""Time-boxed random campaign against the CPU oracle (developer tool; the seeded cases in tests/ are the
+regression suite, this looks for what they do not cover).
+
+Barycentric: random d (1..10), node counts (1..24, product <= 3e5), domains with large offsets and tiny
+widths, derivative specs up to order 3, exact-node coordinates, batch sizes around every tile boundary,
+every kernel form the shape admits (auto / rows / MFMA 16x16x4 / 4x4x4 / lane-per-point) -- each against
+the oracle at 1e-12 of max(|ref|, |T'|) and against each other.
+TT: random d (1..12), ranks (1..20, a few up to 70), node counts (2..16), random dim_order, all forms
+the model admits, against the oracle at 1e-12.
+
+    python tools/fuzz_campaign.py --seconds 240 [--seed S]
+Prints one line per failure (with the seed to reproduce) and a summary; exit code 1 on any failure.
+"""
+import argparse
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import oracle  # noqa: E402  (developer tool: the oracle is the checker)
+from pychebyshev_amd import ChebyshevApproximation, ChebyshevTT, _lib  # noqa: E402
+
+
+def bary_case(rng, stats):
+    d = int(rng.integers(1, 11))
+    cap = 24 if d <= 2 else (16 if d <= 4 else (7 if d <= 6 else 3))
+    while True:
+        shape = tuple(int(rng.integers(1, cap + 1)) for _ in range(d))
+        if np.prod(shape) <= 300_000:
+            break
+    dom = []
+    for _ in range(d):
+        off = float(rng.choice([0.0, 1.0, -5.0, 100.0, 1e4, -1e6]))
+        w = float(rng.choice([1e-3, 0.1, 1.0, 7.0, 1e3]))
+        dom.append([off, off + w])
+    T = rng.standard_normal(shape) * float(rng.choice([1e-6, 1.0, 1e5]))
+    c = ChebyshevApproximation.from_values(T, d, dom, list(shape), max_derivative_order=3)
+    npts = int(rng.choice([1, 2, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 1000, 4097]))
+    pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+    for _ in range(min(npts, 4)):                                  # exact-node coordinates
+        k = int(rng.integers(d))
+        pts[int(rng.integers(npts)), k] = c.nodes[k][int(rng.integers(shape[k]))]
+    spec = [0] * d
+    if rng.random() < 0.6:
+        for _ in range(int(rng.integers(1, 3))):
+            k = int(rng.integers(d))
+            if shape[k] > 3:
+                spec[k] = min(3, spec[k] + int(rng.integers(1, 3)))
+    om = oracle.BaryModel(c.nodes, c.weights, c.diff_matrices, c.tensor_values)
+    ref = oracle.bary_eval_batch(om, pts, spec)
+    Td = T
+    for k in range(d):
+        for _ in range(spec[k]):
+            Td = np.moveaxis(np.moveaxis(Td, k, -1) @ c.diff_matrices[k].T, -1, k)
+    scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(Td))), 1e-300)
+    m = c._model()
+    fails = []
+    for variant in (0, 1, 2, 3, 4):
+        if variant and m.lib.pcx_bary_set_kernel(m.handle, variant) != 0:
+            continue
+        got = c.vectorized_eval_batch(pts, spec)
+        err = float(np.max(np.abs(got - ref))) / scale if np.isfinite(got).all() else float("inf")
+        stats["bary_launches"] += 1
+        stats["bary_worst"] = max(stats["bary_worst"], err)
+        if not err <= 1e-12:
+            fails.append(f"bary shape={shape} dom={dom} spec={spec} N={npts} variant={variant} err={err:.3e}")
+    return fails
+
+
+def tt_case(rng, stats):
+    d = int(rng.integers(1, 13))
+    big = rng.random() < 0.1
+    ranks = [1] + [int(rng.integers(1, 71 if big else 21)) for _ in range(d - 1)] + [1]
+    n = [int(rng.integers(2, 17)) for _ in range(d)]
+    cores = [rng.standard_normal((ranks[k], n[k], ranks[k + 1])) / np.sqrt(ranks[k] * n[k]) for k in range(d)]
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-50, 50, d), rng.choice([1e-2, 1.0, 40.0], d))]
+    order = [int(v) for v in rng.permutation(d)] if rng.random() < 0.5 else None
+    tt = ChebyshevTT.from_coeff_cores(cores, dom, dim_order=order)
+    npts = int(rng.choice([1, 15, 16, 17, 63, 64, 65, 255, 256, 257, 5000]))
+
+    def user_points(count):
+        """`dom` is in the storage frame (as the cores); user column dim_order[k] holds storage dimension k."""
+        st = np.column_stack([rng.uniform(lo, hi, count) for lo, hi in dom])
+        if order is None:
+            return st
+        us = np.empty_like(st)
+        us[:, order] = st
+        return us
+
+    pts = user_points(npts)
+    if npts > 2:
+        corner_lo, corner_hi = np.array([lo for lo, _ in dom]), np.array([hi for _, hi in dom])
+        if order is not None:
+            corner_lo, corner_hi = corner_lo[np.argsort(order)], corner_hi[np.argsort(order)]
+        pts[0], pts[1] = corner_lo, corner_hi
+    ref = oracle.tt_eval_batch(cores, dom, pts, order)
+    # the size of the function, not of one (possibly cancelling) value: a few hundred more points
+    scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(oracle.tt_eval_batch(cores, dom, user_points(300), order)))),
+                1e-300)
+    t = tt._dev()
+    fails = []
+    for variant in (0, 1, 2, 3):
+        if variant and t.lib.pcx_tt_set_kernel(t.handle, variant) != 0:
+            continue
+        got = tt.eval_batch(pts)
+        err = float(np.max(np.abs(got - ref))) / scale if np.isfinite(got).all() else float("inf")
+        stats["tt_launches"] += 1
+        stats["tt_worst"] = max(stats["tt_worst"], err)
+        if not err <= 1e-12:
+            fails.append(f"tt d={d} ranks={ranks} n={n} order={order} N={npts} variant={variant} err={err:.3e}")
+    return fails
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=None, help="with --kind: reproduce exactly this case and stop")
+    ap.add_argument("--kind", choices=["bary", "tt"], default=None)
+    args = ap.parse_args()
+    oracle.build()
+    seed0 = args.seed if args.seed is not None else int(time.time())
+    stats = {"bary_launches": 0, "tt_launches": 0, "bary_worst": 0.0, "tt_worst": 0.0}
+    failures, cases, t0, last = [], 0, time.time(), time.time()
+    while time.time() - t0 < args.seconds:
+        seed = seed0 + cases
+        rng = np.random.default_rng(seed)
+        try:
+            kind = args.kind or ("bary" if cases % 2 == 0 else "tt")
+            fails = (bary_case if kind == "bary" else tt_case)(rng, stats)
+        except Exception as exc:                       # noqa: BLE001 -- an exception is a finding too
+            kind = args.kind or ("bary" if cases % 2 == 0 else "tt")
+            fails = [f"exception {type(exc).__name__}: {exc}"]
+        for f in fails:
+            failures.append(f"seed {seed} ({kind}): {f}")
+            print("FAIL", failures[-1], flush=True)
+        cases += 1
+        if time.time() - last > 30:
+            last = time.time()
+            print(f"... {cases} cases, {len(failures)} failures, worst bary {stats['bary_worst']:.2e} tt {stats['tt_worst']:.2e}",
+                  flush=True)
+        if args.seed is not None and (args.kind is not None or cases >= 2):
+            break
+    print(f"fuzz campaign: first seed {seed0}, {cases} cases, {stats['bary_launches']} barycentric and {stats['tt_launches']} TT "
+          f"evaluations against the oracle; worst error / scale: barycentric {stats['bary_worst']:.2e}, TT {stats['tt_worst']:.2e} "
+          f"(bar 1e-12); failures: {len(failures)}")
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
