@@ -116,11 +116,80 @@ def tt_case(rng, stats):
     return fails
 
 
+def spline_case(rng, stats):
+    """Random spline (1..3-D, 1..4 knots per dimension, from_values pieces), points incl. exact knots and NaN-free
+    out-of-domain rows, one or several specs, against the oracle's routed evaluation."""
+    from pychebyshev_amd import ChebyshevSpline
+    d = int(rng.integers(1, 4))
+    n = [int(rng.integers(3, 10)) for _ in range(d)]
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-10, 10, d), rng.choice([0.5, 2.0, 30.0], d))]
+    knots = []
+    for lo, hi in dom:
+        kk = int(rng.integers(0, 5 if d < 3 else 3))
+        knots.append(sorted(float(v) for v in rng.uniform(lo + 0.05 * (hi - lo), hi - 0.05 * (hi - lo), kk)))
+    grid = ChebyshevSpline.nodes(d, dom, n, knots)
+    values = [rng.standard_normal(tuple(n)) for _ in range(len(grid["pieces"]))] if "pieces" in grid else None
+    if values is None:
+        raise RuntimeError("ChebyshevSpline.nodes() has no 'pieces' entry")
+    sp = ChebyshevSpline.from_values(values, d, dom, n, knots)
+    npts = int(rng.choice([1, 63, 64, 65, 1000, 4096, 4097, 20000]))
+    pts = np.column_stack([rng.uniform(lo - 0.01 * (hi - lo), hi + 0.01 * (hi - lo), npts) for lo, hi in dom])
+    for k in range(d):
+        if knots[k] and npts > k:
+            pts[k, k] = knots[k][0]                                   # exactly on a knot (value specs only)
+    spec = [0] * d
+    models = [oracle.BaryModel(p.nodes, p.weights, p.diff_matrices, p.tensor_values) for p in sp._pieces]
+    fails = []
+    for spec in ([0] * d, [1] + [0] * (d - 1)):
+        rows = np.arange(npts) if not any(spec) else np.arange(min(d, npts), npts)
+        if len(rows) == 0:
+            continue
+        ref = oracle.spline_eval_batch(models, sp.knots, sp._shape, pts[rows], spec)
+        got = sp.eval_batch(pts[rows], spec)
+        scale = max(float(np.max(np.abs(ref))), max(float(np.max(np.abs(v))) for v in values) *
+                    (1.0 if not any(spec) else float(np.max(np.abs(sp._pieces[0].diff_matrices[0])))))
+        err = float(np.max(np.abs(got - ref))) / scale if np.isfinite(got).all() else float("inf")
+        stats["spline_launches"] = stats.get("spline_launches", 0) + 1
+        stats["spline_worst"] = max(stats.get("spline_worst", 0.0), err)
+        if not err <= 1e-12:
+            fails.append(f"spline d={d} n={n} knots={knots} dom={dom} spec={spec} N={npts} err={err:.3e}")
+    return fails
+
+
+def multi_case(rng, stats):
+    """m derivative specs in one call (1..70, beyond the 64 of one launch) = the specs one by one, bit for bit."""
+    d = int(rng.integers(1, 6))
+    cap = 12 if d <= 3 else 6
+    shape = [int(rng.integers(3, cap + 1)) for _ in range(d)]
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-5, 5, d), rng.uniform(0.1, 10, d))]
+    c = ChebyshevApproximation.from_values(rng.standard_normal(shape), d, dom, shape, max_derivative_order=3)
+    m = int(rng.choice([1, 2, 6, 63, 64, 65, 70]))
+    specs = [[int(v) for v in rng.integers(0, 3, d)] for _ in range(m)]
+    npts = int(rng.choice([1, 33, 500, 3000]))
+    pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+    got = c.vectorized_eval_multi_batch(pts, specs)
+    fails = []
+    for j in rng.choice(m, min(m, 6), replace=False):
+        one = c.vectorized_eval_batch(pts, specs[int(j)])
+        stats["multi_launches"] = stats.get("multi_launches", 0) + 1
+        if not np.array_equal(got[:, int(j)], one):
+            # the multi-spec launch may take another kernel form than the single-spec one: then 1e-12 is the bar
+            scale = max(float(np.max(np.abs(one))), 1e-300)
+            err = float(np.max(np.abs(got[:, int(j)] - one))) / scale
+            stats["multi_worst"] = max(stats.get("multi_worst", 0.0), err)
+            if not err <= 1e-12:
+                fails.append(f"multi shape={shape} m={m} spec={specs[int(j)]} N={npts} err={err:.3e}")
+    return fails
+
+
+KINDS = {"bary": bary_case, "tt": tt_case, "spline": spline_case, "multi": multi_case}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=None, help="with --kind: reproduce exactly this case and stop")
-    ap.add_argument("--kind", choices=["bary", "tt"], default=None)
+    ap.add_argument("--kind", choices=list(KINDS), default=None)
     args = ap.parse_args()
     oracle.build()
     seed0 = args.seed if args.seed is not None else int(time.time())
@@ -130,10 +199,9 @@ def main():
         seed = seed0 + cases
         rng = np.random.default_rng(seed)
         try:
-            kind = args.kind or ("bary" if cases % 2 == 0 else "tt")
-            fails = (bary_case if kind == "bary" else tt_case)(rng, stats)
+            kind = args.kind or ("bary", "tt", "bary", "tt", "spline", "multi")[cases % 6]
+            fails = KINDS[kind](rng, stats)
         except Exception as exc:                       # noqa: BLE001 -- an exception is a finding too
-            kind = args.kind or ("bary" if cases % 2 == 0 else "tt")
             fails = [f"exception {type(exc).__name__}: {exc}"]
         for f in fails:
             failures.append(f"seed {seed} ({kind}): {f}")
@@ -145,9 +213,11 @@ def main():
                   flush=True)
         if args.seed is not None and (args.kind is not None or cases >= 2):
             break
-    print(f"fuzz campaign: first seed {seed0}, {cases} cases, {stats['bary_launches']} barycentric and {stats['tt_launches']} TT "
-          f"evaluations against the oracle; worst error / scale: barycentric {stats['bary_worst']:.2e}, TT {stats['tt_worst']:.2e} "
-          f"(bar 1e-12); failures: {len(failures)}")
+    print(f"fuzz campaign: first seed {seed0}, {cases} cases, {stats['bary_launches']} barycentric, {stats['tt_launches']} TT and "
+          f"{stats.get('spline_launches', 0)} spline evaluations against the oracle, {stats.get('multi_launches', 0)} multi-spec columns "
+          f"against single-spec calls; worst error / scale: barycentric {stats['bary_worst']:.2e}, TT {stats['tt_worst']:.2e}, "
+          f"spline {stats.get('spline_worst', 0.0):.2e}, multi-spec {stats.get('multi_worst', 0.0):.2e} (bar 1e-12); "
+          f"failures: {len(failures)}")
     return 1 if failures else 0
 
 
