@@ -65,7 +65,7 @@ def main():
           f"{'mfma pts/s':>11} {'fp64':>6}   {'rows pts/s':>11} {'fp64':>6}")
     shapes = [(11,) * 5, (7,) * 5, (5,) * 6, (15,) * 4, (21,) * 3, (33, 33), (64, 64), (200,), (12, 12), (9, 7, 6),
               (6, 6, 6, 6), (8, 8, 8), (16, 16, 16), (11, 11, 11), (9, 11, 13, 7), (4,) * 8, (3,) * 10, (6, 11, 11, 11, 11),
-              (11, 11, 11, 11, 6), (16,) * 4, (20,) * 3, (65,) * 3, (64,) * 4]
+              (11, 11, 11, 11, 6), (16,) * 4, (20,) * 3, (17,) * 3, (30,) * 3, (40,) * 3, (10, 10, 10, 10), (65,) * 3, (64,) * 4]
     for shape in shapes:
         size = int(np.prod(shape))
         npts = 4 * a.points if size <= 2000 else (a.points if size < 4_000_000 else a.points // 8)
