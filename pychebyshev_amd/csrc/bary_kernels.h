@@ -106,6 +106,20 @@ __device__ __forceinline__ double code_weight(unsigned code, const double *bw_co
     return (w0 * w1) * (w2 * w3);
 }
 
+// NF live fields, known at compile time (fields are filled low first; a dead field names the all-ones row and
+// a product with exactly 1.0 changes nothing: bit-identical to code_weight).  NF = 2 serves short plans whose
+// head has at most two dimensions: their few matrix instructions per tile cost no more than these look-ups.
+template <int NF>
+__device__ __forceinline__ double code_weight_t(unsigned code, const double *bw_col, int PW) {
+    if constexpr (NF >= 4) return code_weight(code, bw_col, PW);
+    else {
+        double w0 = bw_col[(code & 255u) * PW];
+        double w1 = bw_col[((code >> 8) & 255u) * PW];
+        if constexpr (NF == 3) return (w0 * w1) * bw_col[((code >> 16) & 255u) * PW];
+        else return w0 * w1;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // K1+K2 fused, MFMA form.  One wave owns PW = 16*NT query points.
 //
@@ -134,7 +148,7 @@ __device__ __forceinline__ double code_weight(unsigned code, const double *bw_co
 
 // WIDE: more than four head or tail dimensions (d up to 16): every code has a second word
 // (rowcode_hi / kcode_hi, fields 4..7) and a weight is the product of both words' products.
-template <int KS, int NT, bool WIDE>
+template <int KS, int NT, bool WIDE, int NF = 4>
 __global__ void __launch_bounds__(256, 2)
 k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             const double *__restrict__ wts, const double *const *__restrict__ frag_tab,
@@ -261,13 +275,15 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                            for (int f = 0; f < 4; ++f)
+                            for (int f = 0; f < (NF < 4 ? NF : 4); ++f)          // dead fields name the ones row: not read
                                 wr[j][nt][f] = bw[(size_t)((cc[j] >> (8 * f)) & 255u) * PW + 16 * nt + c];
                     }
                     if (s == 2 * j + 2) {
 #pragma unroll
                         for (int nt = 0; nt < NT; ++nt)
-                            w[nt][j] = (wr[j][nt][0] * wr[j][nt][1]) * (wr[j][nt][2] * wr[j][nt][3]);
+                            w[nt][j] = NF >= 4 ? (wr[j][nt][0] * wr[j][nt][1]) * (wr[j][nt][2] * wr[j][nt][3])
+                                     : (NF == 3 ? (wr[j][nt][0] * wr[j][nt][1]) * wr[j][nt][2]
+                                                : wr[j][nt][0] * wr[j][nt][1]);
                     }
                     if (WIDE && s == 2 * j + 1) {
 #pragma unroll
@@ -293,7 +309,7 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             for (int j = 0; j < 4; ++j) {
                 unsigned code = rowcode[16 * t + g + 4 * j];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) w[nt][j] = code_weight(code, bw + 16 * nt + c, PW);
+                for (int nt = 0; nt < NT; ++nt) w[nt][j] = code_weight_t<NF>(code, bw + 16 * nt + c, PW);
                 if (WIDE) {
                     unsigned hi = rowcode_hi[16 * t + g + 4 * j];
 #pragma unroll

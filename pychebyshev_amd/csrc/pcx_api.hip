@@ -758,13 +758,13 @@ static int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **ou
 // batches are split over grid.y (chunks of row tiles) so that a handful of points still
 // uses the whole chip; the per-chunk totals are then added by k_bary_reduce in the fixed
 // chunk order, which makes every result independent of the batch size.
-template <int KS, int NT, bool WIDE>
+template <int KS, int NT, bool WIDE, int NF = 4>
 static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
                          double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
                          const int *perm) {
     const bool allow_split = split_scratch != nullptr;
     size_t lds = mfma_lds_bytes(h->dims, NT);
-    auto kern = k_bary_mfma<KS, NT, WIDE>;
+    auto kern = k_bary_mfma<KS, NT, WIDE, NF>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long per_wg = 4L * 16 * NT;
@@ -826,12 +826,14 @@ static int launch_mfma4(pcx_bary *h, const double *const *frag_tab, int m, const
     return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d", h->plan.KS);
 }
 
-template <int NT, bool WIDE>
-static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
+// NF: live fields of a row code = head dimensions (1..4), known per handle: the kernel reads only those
+// (16 LDS reads and multiplies fewer per row tile with a two-dimensional head; 11^5, head of three: +1.4 %).
+template <int NT, bool WIDE, int NF>
+static int launch_mfma_nf(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
                           double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
                           const int *perm) {
     switch (h->plan.KS) {
-#define CASE_KS(v) case v: return launch_mfma_t<v, NT, WIDE>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+#define CASE_KS(v) case v: return launch_mfma_t<v, NT, WIDE, NF>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
         CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8)
         CASE_KS(9) CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
         CASE_KS(17) CASE_KS(18) CASE_KS(19) CASE_KS(20) CASE_KS(21) CASE_KS(22) CASE_KS(23) CASE_KS(24)
@@ -840,12 +842,25 @@ static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, con
     }
     if constexpr (NT == 1) {
         switch (h->plan.KS) {
-#define CASE_KS(v) case v: return launch_mfma_t<v, 1, WIDE>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+#define CASE_KS(v) case v: return launch_mfma_t<v, 1, WIDE, NF>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
             CASE_KS(36) CASE_KS(40) CASE_KS(44) CASE_KS(48) CASE_KS(52) CASE_KS(56) CASE_KS(60) CASE_KS(64)
 #undef CASE_KS
         }
     }
     return fail(PCX_ERR_UNSUPPORTED, "no MFMA instantiation for KS=%d, NT=%d", h->plan.KS, NT);
+}
+
+template <int NT, bool WIDE>
+static int launch_mfma_nt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N,
+                          double *d_out, long ostride, long ooff, hipStream_t st, Scratch *split_scratch,
+                          const int *perm) {
+    if constexpr (!WIDE) {
+        if (h->plan.split <= 2)
+            return launch_mfma_nf<NT, false, 2>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+        if (h->plan.split == 3)
+            return launch_mfma_nf<NT, false, 3>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+    }
+    return launch_mfma_nf<NT, WIDE, 4>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
 }
 
 static int launch_rows(pcx_bary *h, const DerivedTensor &dt, const double *d_pts, long N,
