@@ -126,7 +126,7 @@ class Bary5D(Workload):
     d = 5
     flop_per_eval = 354310.0     # 177,155 FMA: 161051 + 14641 + 1331 + 121 + 11
     bytes_per_eval = 48.0        # 5 x 8 in + 8 out
-    kernel = "k_bary_mfma<31,2,false>"
+    kernel = "k_bary_mfma<31,2,false,3>"
 
     def __init__(self, lib_mod, n_points, specs, key):
         from pychebyshev_amd import ChebyshevApproximation
