@@ -109,6 +109,14 @@ __device__ __forceinline__ double code_weight(unsigned code, const double *bw_co
 // NF live fields, known at compile time (fields are filled low first; a dead field names the all-ones row and
 // a product with exactly 1.0 changes nothing: bit-identical to code_weight).  NF = 2 serves short plans whose
 // head has at most two dimensions: their few matrix instructions per tile cost no more than these look-ups.
+// The four row codes of lane group g for tile t (rows g, g + 4, g + 8, g + 12): stored side by side
+// ([t][g][j], see pcx_bary_create), one 16-byte load.
+struct pcx_u4 { unsigned v[4]; };
+__device__ __forceinline__ pcx_u4 load_row_codes(const unsigned *__restrict__ codes, long t, int g) {
+    const uint4 q = reinterpret_cast<const uint4 *>(codes)[4 * t + g];
+    return pcx_u4{{q.x, q.y, q.z, q.w}};
+}
+
 template <int NF>
 __device__ __forceinline__ double code_weight_t(unsigned code, const double *bw_col, int PW) {
     if constexpr (NF >= 4) return code_weight(code, bw_col, PW);
@@ -235,10 +243,15 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) head[i] = 0.0;
     if (PIPELINED && t_begin < t_end) {
+        {
+            const pcx_u4 q = load_row_codes(rowcode, t_begin, g);
+            pcx_u4 qh = q;
+            if (WIDE) qh = load_row_codes(rowcode_hi, t_begin, g);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            cn[j] = rowcode[16 * t_begin + g + 4 * j];
-            if (WIDE) cnh[j] = rowcode_hi[16 * t_begin + g + 4 * j];
+            for (int j = 0; j < 4; ++j) {
+                cn[j] = q.v[j];
+                if (WIDE) cnh[j] = qh.v[j];
+            }
         }
 #pragma unroll
         for (int i = 0; i < DEPTH; ++i) head[i] = tf[((size_t)t_begin * KS + i) * 64];
@@ -256,11 +269,16 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             unsigned cc[4], cch[4];
 #pragma unroll
             for (int i = 0; i < DEPTH; ++i) ring[i] = head[i];
+            {
+                const pcx_u4 q = load_row_codes(rowcode, t_next, g);
+                pcx_u4 qh = q;
+                if (WIDE) qh = load_row_codes(rowcode_hi, t_next, g);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                cc[j] = cn[j];
-                cn[j] = rowcode[16 * t_next + g + 4 * j];
-                if (WIDE) { cch[j] = cnh[j]; cnh[j] = rowcode_hi[16 * t_next + g + 4 * j]; }
+                for (int j = 0; j < 4; ++j) {
+                    cc[j] = cn[j];
+                    cn[j] = q.v[j];
+                    if (WIDE) { cch[j] = cnh[j]; cnh[j] = qh.v[j]; }
+                }
             }
             double wr[4][NT][4];          // raw table entries of row j, looked up at k-step 2j
             double wh[4][NT][4];          // ... and of its second code word (wide plans), at k-step 2j + 1
@@ -305,13 +323,16 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
+            const pcx_u4 q = load_row_codes(rowcode, t, g);
+            pcx_u4 qh = q;
+            if (WIDE) qh = load_row_codes(rowcode_hi, t, g);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                unsigned code = rowcode[16 * t + g + 4 * j];
+                unsigned code = q.v[j];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) w[nt][j] = code_weight_t<NF>(code, bw + 16 * nt + c, PW);
                 if (WIDE) {
-                    unsigned hi = rowcode_hi[16 * t + g + 4 * j];
+                    unsigned hi = qh.v[j];
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) w[nt][j] *= code_weight(hi, bw + 16 * nt + c, PW);
                 }
@@ -474,8 +495,8 @@ k_bary_mfma4(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             }
         }
         // the tile's four row codes of this lane group, fetched before the MFMA chains
-        const unsigned code0 = rowcode[16 * t + g], code1 = rowcode[16 * t + 4 + g];
-        const unsigned code2 = rowcode[16 * t + 8 + g], code3 = rowcode[16 * t + 12 + g];
+        const pcx_u4 q4 = load_row_codes(rowcode, t, g);
+        const unsigned code0 = q4.v[0], code1 = q4.v[1], code2 = q4.v[2], code3 = q4.v[3];
         // two row groups at a time: four independent accumulator chains, and the broadcast
         // LDS reads of the next DEPTH k-steps are in flight while the current one multiplies
 #pragma unroll

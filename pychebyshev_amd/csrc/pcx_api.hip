@@ -542,6 +542,17 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
             kcode[kk] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
             kcode_hi[kk] = f[4] | (f[5] << 8) | (f[6] << 16) | (f[7] << 24);
         }
+        // device layout of the row codes: the four codes a lane needs for a tile (rows g, g+4, g+8, g+12 of
+        // tile t) side by side, [t][g][j], so that one 16-byte load fetches them
+        auto lane_order = [&](std::vector<unsigned> &v) {
+            std::vector<unsigned> o(v.size());
+            for (long t = 0; t < (long)p.MT; ++t)
+                for (int g = 0; g < 4; ++g)
+                    for (int j = 0; j < 4; ++j) o[(size_t)(4 * t + g) * 4 + j] = v[(size_t)16 * t + g + 4 * j];
+            v.swap(o);
+        };
+        lane_order(rowcode);
+        lane_order(rowcode_hi);
         if (h->wide) {
             CREATE_TRY(hipMalloc((void **)&h->d_rowcode_hi, rowcode_hi.size() * sizeof(unsigned)));
             CREATE_TRY(hipMalloc((void **)&h->d_kcode_hi, kcode_hi.size() * sizeof(unsigned)));
