@@ -31,8 +31,10 @@ Also on the JSON line:
                HBM bytes per launch from the committed PMC profile (cached; see
                traffic_source), not collected in this run.
   end_to_end   the host-pointer entry point on the same batch (H2D + kernel + D2H).
-  greeks, tt   companions: config 4 (6 derivative specs) and config 3 (TT-Cross build +
-               10^7-point eval_batch), same timing discipline, never mixed into `value`.
+  greeks, tt, tt10d
+               companions: config 4 (6 derivative specs), config 3 (TT-Cross build + 10^7-point
+               eval_batch) and config 5's model at a per-GPU batch (10-D, rank 16, 4x10^6 points),
+               same timing discipline, never mixed into `value`.
   cpu_baseline the CPU oracle (C restatement of the reference, OpenMP) on all usable
                host cores, on the per-GPU CPU share (16) and the reference's NumPy shape on
                one core -- bounded samples of the same workload, rank 0, N = 1 only.
@@ -652,7 +654,7 @@ def run_rank(args) -> int:
     # same discipline and reports them beside the headline value, never mixed into it
     companions = {}
     if args.workload == "bary5d" and not args.no_companion:
-        for name, field in (("greeks5d", "greeks"), ("tt5d", "tt")):
+        for name, field in (("greeks5d", "greeks"), ("tt5d", "tt"), ("tt10d", "tt10d")):
             got = companion(name)
             if got is None:
                 continue
@@ -751,7 +753,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true",
                     help="skip the CPU baseline and the host-pointer end_to_end legs")
     ap.add_argument("--no-companion", action="store_true",
-                    help="bary5d only: skip the Greeks (config 4) and TT (config 3) companions")
+                    help="bary5d only: skip the Greeks (config 4), TT (config 3) and 10-D TT (config 5) companions")
     ap.add_argument("--gather", default="auto", choices=["auto", "none", "rccl", "rccl+d2h", "d2h"],
                     help="what each timed step of the headline does with the result blocks (N > 1)")
     ap.add_argument("--variant", type=int, default=0,
