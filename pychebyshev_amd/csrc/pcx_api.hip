@@ -1730,6 +1730,7 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
         h->dims.col[k] = col;
         h->dims.lo[k] = lo[k];
         h->dims.hi[k] = hi[k];
+        h->dims.scale[k] = 2.0 / (hi[k] - lo[k]);
         coff[k] = core_total;
         core_total += (long)ranks[k] * n_nodes[k] * ranks[k + 1];
         h->rmax = std::max(h->rmax, std::max(ranks[k], ranks[k + 1]));

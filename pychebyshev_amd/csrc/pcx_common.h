@@ -45,5 +45,6 @@ struct TTDims {
     int col[PCX_MAX_DIMS];        // user column read by storage position k (dim_order)
     double lo[PCX_MAX_DIMS];
     double hi[PCX_MAX_DIMS];
+    double scale[PCX_MAX_DIMS];   // 2 / (hi - lo): s = fma(x - lo, scale, -1) without a division per point
     long frag_off[PCX_MAX_DIMS];  // offset (doubles) of storage dim k in the packed cores
 };

@@ -153,7 +153,7 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
         for (int nt = 0; nt < NT; ++nt) {
             v0[nt][0] = (g == 0) ? 1.0 : 0.0;
             double x = xs[(16 * nt + c16) * d + dims.col[0]];
-            s[nt] = 2.0 * (x - dims.lo[0]) / (dims.hi[0] - dims.lo[0]) - 1.0;   // tensor_train.py:2254
+            s[nt] = __builtin_fma(x - dims.lo[0], dims.scale[0], -1.0);   // tensor_train.py:2254, 2 / (hi - lo) from the host
 #pragma unroll
             for (int t = 0; t < RT; ++t) acc[nt][t] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
         }
@@ -168,13 +168,13 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
     }
 
     for (int k = 1; k < d - 1; ++k) {
-        const double lo = dims.lo[k], hi = dims.hi[k];
+        const double lo = dims.lo[k], sck = dims.scale[k];
         double s[NT];
         pcx_d4 acc[NT][RT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             double x = xs[(16 * nt + c16) * d + dims.col[k]];
-            s[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;
+            s[nt] = __builtin_fma(x - lo, sck, -1.0);
 #pragma unroll
             for (int t = 0; t < RT; ++t) acc[nt][t] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
         }
@@ -191,12 +191,12 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
     {
         const int k = d - 1;
         const int n = dims.n[k];
-        const double lo = dims.lo[k], hi = dims.hi[k];
+        const double lo = dims.lo[k], sck = dims.scale[k];
         double sc[NT], tp[NT], tc[NT], w[NT][RC];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             double x = xs[(16 * nt + c16) * d + dims.col[k]];
-            sc[nt] = 2.0 * (x - lo) / (hi - lo) - 1.0;
+            sc[nt] = __builtin_fma(x - lo, sck, -1.0);
             tp[nt] = 1.0;
             tc[nt] = sc[nt];
 #pragma unroll
