@@ -7,6 +7,7 @@ but it travels to the GPU box with the repo snapshot).
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -45,8 +46,42 @@ def _deps(src: str):
     return [os.path.join(CSRC, src)] + [os.path.join(CSRC, h) for h in SOURCES[src]] + [os.path.abspath(__file__)]
 
 
+STAMP = LIB + ".stamp"      # digest of the sources the library was built from (travels with it)
+
+
+def _tu_digest(src: str) -> str:
+    """Content hash of one translation unit, its headers and the compile flags: independent of file
+    times (a copied checkout may not keep them)."""
+    h = hashlib.sha256()
+    h.update((" ".join(FLAGS) + ARCH).encode())
+    for f in _deps(src)[:-1]:
+        if os.path.exists(f):
+            h.update(os.path.basename(f).encode())
+            with open(f, "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def _source_digest() -> str:
+    return hashlib.sha256("".join(_tu_digest(src) for src in sorted(SOURCES)).encode()).hexdigest()
+
+
+def _read(path: str) -> str:
+    try:
+        with open(path) as fh:
+            return fh.read().strip()
+    except OSError:
+        return ""
+
+
 def needs_build() -> bool:
-    return any(_newer(LIB, _deps(src)) for src in SOURCES)
+    if not os.path.exists(LIB):
+        return True
+    try:
+        with open(STAMP) as fh:
+            return fh.read().strip() != _source_digest()        # decided by content when a stamp exists
+    except OSError:
+        return any(_newer(LIB, _deps(src)) for src in SOURCES)
 
 
 def _run(cmd, verbose):
@@ -70,9 +105,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
-        if force or _newer(obj, _deps(src)):
+        if force or not os.path.exists(obj) or _read(obj + ".stamp") != _tu_digest(src):
             _run([hipcc, f"--offload-arch={ARCH}", "-c"] + FLAGS + ["-o", obj, os.path.join(CSRC, src)], verbose)
+            with open(obj + ".stamp", "w") as fh:
+                fh.write(_tu_digest(src) + "\n")
     _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], verbose)
+    with open(STAMP, "w") as fh:
+        fh.write(_source_digest() + "\n")
     return LIB
 
 
