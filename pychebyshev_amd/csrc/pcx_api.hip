@@ -1955,7 +1955,8 @@ static int tt_launch_d4(pcx_tt *h, const double *d_pts, long N, double *d_out, h
     }
     long batches = (N + 63) / 64;
     // persistent workgroups, four per resident slot: later rounds of workgroups even out the tail
-    long blocks = std::min<long>(batches, h->d4_resident * 4);
+    static const int mult = [] { const char *e = getenv("PCX_D4_MULT"); return e ? std::max(1, atoi(e)) : 4; }();
+    long blocks = std::min<long>(batches, h->d4_resident * mult);
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), lds, st, h->dims, h->d4plan, h->d_img4, d_pts, d_out, N);
     HIP_TRY(hipGetLastError());
     return PCX_OK;
