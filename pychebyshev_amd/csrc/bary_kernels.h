@@ -741,22 +741,14 @@ struct BarySmallScale {
     double s[4];            // 2^e per dimension (d <= 4)
 };
 
+// The body shared by the single-tensor kernel and the all-pieces-of-a-spline kernel: weights of the lane's
+// point (row `row` of pts; an invalid lane computes on a node and stores nothing), then every tensor.
 template <int DOUT, int NLP>
-__global__ void __launch_bounds__(64)
-k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, const double *__restrict__ nodes,
-             const double *__restrict__ wts, const double *__restrict__ T, const double *const *__restrict__ T_tab,
-             int m, const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
-             const int *__restrict__ perm) {
-    // m derivative specs in one launch (T_tab: device table of m tensors; NULL: the single tensor T):
-    // the weights of a point are formed once and every tensor is contracted with them.
-    extern __shared__ double lds[];
-    const int lane = threadIdx.x;
-    const long pidx = (long)blockIdx.x * 64 + lane;
-    const bool valid = pidx < N;
-    const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
+__device__ __forceinline__ void bary_small_body(const BaryDims &dims, const BarySmallScale &sc, pcx_cptr csn, pcx_cptr cnd,
+                                                pcx_cptr cw, const double *T, const double *const *T_tab, int m,
+                                                const double *__restrict__ pts, double *__restrict__ out, bool valid,
+                                                long row, long ostride, long ooff, double *bw_lane) {
     const int d = DOUT + 1;
-    double *bw_lane = lds + lane;
-    const pcx_cptr csn = pcx_as_constant(snodes), cw = pcx_as_constant(wts), cnd = pcx_as_constant(nodes);
 #pragma unroll
     for (int k = 0; k < DOUT; ++k) {
         const double x = valid ? pts[row * d + k] : cnd[dims.off[k]];
@@ -781,6 +773,56 @@ k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes
             if (valid) out[row * ostride + ooff + z] = y;
         }
     }
+}
+
+template <int DOUT, int NLP>
+__global__ void __launch_bounds__(64)
+k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, const double *__restrict__ nodes,
+             const double *__restrict__ wts, const double *__restrict__ T, const double *const *__restrict__ T_tab,
+             int m, const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
+             const int *__restrict__ perm) {
+    // m derivative specs in one launch (T_tab: device table of m tensors; NULL: the single tensor T):
+    // the weights of a point are formed once and every tensor is contracted with them.
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long pidx = (long)blockIdx.x * 64 + lane;
+    const bool valid = pidx < N;
+    const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
+    bary_small_body<DOUT, NLP>(dims, sc, pcx_as_constant(snodes), pcx_as_constant(nodes), pcx_as_constant(wts), T, T_tab, m,
+                               pts, out, valid, row, ostride, ooff, lds + lane);
+}
+
+// All pieces of a piecewise interpolant in ONE launch (pieces of equal shape on the lane-per-point kernel):
+// a launch per piece is launch-bound once a spline has tens of pieces (64 pieces x 15 k points: 0.46 ms even
+// fanned over four streams).  Workgroup b serves 64 consecutive slots of piece blk_piece[b]'s bucket, starting
+// at slot blk_first[b] of the bucket permutation; the piece's model (scaled nodes, weights, tensor or tensor
+// table, scale) comes from a device table indexed by the piece -- wave-uniform, i.e. scalar loads.
+struct SplinePieceModel {
+    const double *snodes, *nodes, *wts;
+    const double *T;                    // the piece's tensor (m == 1) ...
+    const double *const *T_tab;         // ... or its device table of m tensors (NULL when m == 1)
+    BarySmallScale sc;
+};
+
+template <int DOUT, int NLP>
+__global__ void __launch_bounds__(64)
+k_bary_small_pieces(BaryDims dims, const SplinePieceModel *__restrict__ models, const int *__restrict__ blk_piece,
+                    const int *__restrict__ blk_first, const int *__restrict__ piece_end, int m,
+                    const double *__restrict__ pts, double *__restrict__ out, long ostride, long ooff,
+                    const int *__restrict__ perm) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int piece = blk_piece[blockIdx.x];
+    const long pidx = (long)blk_first[blockIdx.x] + lane;
+    const bool valid = pidx < (long)piece_end[piece];
+    const long row = valid ? (long)perm[pidx] : 0;
+    typedef const SplinePieceModel __attribute__((address_space(4))) *model_cptr;
+    const model_cptr mp = (model_cptr)(unsigned long long)(models + piece);
+    BarySmallScale sc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sc.s[k] = mp->sc.s[k];
+    bary_small_body<DOUT, NLP>(dims, sc, pcx_as_constant(mp->snodes), pcx_as_constant(mp->nodes), pcx_as_constant(mp->wts),
+                               mp->T, mp->T_tab, m, pts, out, valid, row, ostride, ooff, lds + lane);
 }
 
 // ---------------------------------------------------------------------------------

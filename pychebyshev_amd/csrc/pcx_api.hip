@@ -1224,6 +1224,12 @@ struct pcx_spline {
     hipEvent_t ev_fork = nullptr, ev_join[kSide] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
     Scratch s_pts, s_out, s_piece, s_perm, s_partial;
+    // one launch for all pieces (pieces of equal shape on the lane-per-point kernel): per-piece model table,
+    // per-workgroup (piece, first slot) lists; staged through a pinned host buffer
+    bool fused_ok = false;
+    Scratch s_models, s_blk;
+    void *pin_stage = nullptr;
+    size_t pin_cap = 0;
 };
 
 extern "C" int pcx_spline_destroy(pcx_spline *h) {
@@ -1233,6 +1239,8 @@ extern "C" int pcx_spline_destroy(pcx_spline *h) {
     (void)hipFree(h->d_knots);
     (void)hipFree(h->d_counts);
     h->s_pts.release(); h->s_out.release(); h->s_piece.release(); h->s_perm.release(); h->s_partial.release();
+    h->s_models.release(); h->s_blk.release();
+    if (h->pin_stage) (void)hipHostFree(h->pin_stage);
     for (int i = 0; i < pcx_spline::kSide; ++i) {
         if (h->side[i]) { (void)hipStreamSynchronize(h->side[i]); (void)hipStreamDestroy(h->side[i]); }
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
@@ -1275,6 +1283,16 @@ extern "C" int pcx_spline_create(int device, int d, const int32_t *n_knots, cons
         h->pieces.push_back(pieces[i]);
     }
     h->n_pieces = n_pieces;
+    {   // the one-launch path: every piece the same shape, all on the lane-per-point kernel (PCX_SPLINE_FUSED=0: off)
+        const pcx_bary *p0 = h->pieces[0];
+        const char *f = getenv("PCX_SPLINE_FUSED");
+        bool ok = n_pieces > 1 && p0->small_nlp > 0 && !(f && f[0] == '0');
+        for (int i = 0; ok && i < n_pieces; ++i) {
+            const pcx_bary *pc = h->pieces[i];
+            ok = pc->small_nlp == p0->small_nlp && memcmp(&pc->dims, &p0->dims, sizeof(BaryDims)) == 0;
+        }
+        h->fused_ok = ok;
+    }
     {   // PCX_SPLINE_GLOBAL_HIST=1 forces the many-pieces routing path (tests)
         const char *g = getenv("PCX_SPLINE_GLOBAL_HIST");
         h->lds_hist = (n_pieces <= PCX_SPLINE_LDS_PIECES && !(g && g[0] == '1')) ? 1 : 0;
@@ -1323,6 +1341,113 @@ static int spline_bucket(pcx_spline *h, const double *dp, long cnt, std::vector<
     return PCX_OK;
 }
 
+template <int DOUT, int NLP>
+static void launch_small_pieces_t(const pcx_bary *p0, const SplinePieceModel *models, const int *blk_piece,
+                                  const int *blk_first, const int *piece_end, int m, long blocks, const double *dp,
+                                  double *dout, const int *perm, hipStream_t st) {
+    auto kern = k_bary_small_pieces<DOUT, NLP>;
+    const size_t lds = (size_t)(p0->dims.sum_n - p0->dims.n[DOUT]) * 64 * sizeof(double);
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(64), lds, st, p0->dims, models, blk_piece, blk_first, piece_end, m,
+                       dp, dout, (long)m, 0L, perm);
+}
+
+template <int DOUT>
+static int launch_small_pieces_d(const pcx_bary *p0, const SplinePieceModel *models, const int *blk_piece,
+                                 const int *blk_first, const int *piece_end, int m, long blocks, const double *dp,
+                                 double *dout, const int *perm, hipStream_t st) {
+    switch (p0->small_nlp) {
+#define CASE_NLP(v) case v: launch_small_pieces_t<DOUT, v>(p0, models, blk_piece, blk_first, piece_end, m, blocks, dp, dout, perm, st); return PCX_OK;
+    CASE_NLP(2) CASE_NLP(3) CASE_NLP(4) CASE_NLP(5) CASE_NLP(6) CASE_NLP(7) CASE_NLP(8) CASE_NLP(9) CASE_NLP(10) CASE_NLP(11)
+    CASE_NLP(12) CASE_NLP(13) CASE_NLP(14) CASE_NLP(15) CASE_NLP(16) CASE_NLP(24) CASE_NLP(32) CASE_NLP(48) CASE_NLP(64)
+#undef CASE_NLP
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
+}
+
+// All non-empty pieces in one launch.  Returns PCX_OK with *done = false when the batch does not qualify
+// (a piece forced onto another kernel form): the caller then launches per piece.
+static int spline_launch_fused(pcx_spline *h, const double *dp, const std::vector<int> &counts,
+                               const std::vector<int> &offsets, const int32_t *derivs, int m, double *dout, bool *done) {
+    *done = false;
+    if (!h->fused_ok || m > kMaxSpecs) return PCX_OK;
+    const int d = h->sd.d;
+    const int np = h->n_pieces;
+    for (int i = 0; i < np; ++i)
+        if (counts[i] && bary_effective_variant(h->pieces[i]) != 4) return PCX_OK;
+    long blocks = 0;
+    for (int i = 0; i < np; ++i) blocks += (counts[i] + 63) / 64;
+    if (blocks == 0) { *done = true; return PCX_OK; }
+    // host staging: [models np][piece_end np][blk_piece blocks][blk_first blocks]
+    const size_t b_models = (size_t)np * sizeof(SplinePieceModel);
+    const size_t b_ints = ((size_t)np + 2 * (size_t)blocks) * sizeof(int);
+    const size_t need = b_models + b_ints;
+    if (need > h->pin_cap) {
+        if (h->pin_stage) (void)hipHostFree(h->pin_stage);
+        h->pin_stage = nullptr;
+        h->pin_cap = 0;
+        HIP_TRY(hipHostMalloc(&h->pin_stage, need * 2, hipHostMallocDefault));
+        h->pin_cap = need * 2;
+    }
+    int rc = h->s_models.reserve(b_models);
+    if (rc) return rc;
+    rc = h->s_blk.reserve(b_ints);
+    if (rc) return rc;
+    SplinePieceModel *hm = (SplinePieceModel *)h->pin_stage;
+    int *h_end = (int *)((char *)h->pin_stage + b_models), *h_piece = h_end + np, *h_first = h_piece + blocks;
+    long b = 0;
+    for (int i = 0; i < np; ++i) {
+        pcx_bary *pc = h->pieces[i];
+        SplinePieceModel mm;
+        mm.snodes = pc->d_snodes; mm.nodes = pc->d_nodes; mm.wts = pc->d_wts;
+        mm.T = nullptr; mm.T_tab = nullptr; mm.sc = pc->small_scale;
+        h_end[i] = offsets[i] + counts[i];
+        if (counts[i]) {
+            std::lock_guard<std::mutex> plk(pc->mu);
+            pc->call_mark = pc->clock;
+            std::vector<DerivedTensor *> dts(m);
+            for (int s = 0; s < m; ++s) {
+                rc = bary_get_tensor(pc, derivs ? derivs + (size_t)s * d : nullptr, &dts[s]);
+                if (rc) return rc;
+            }
+            if (m > 1) {
+                std::vector<double *> tab(m);
+                for (int s = 0; s < m; ++s) tab[s] = dts[s]->plain;
+                if (tab != pc->tab_host) {
+                    HIP_TRY(hipDeviceSynchronize());            // earlier launches (any stream) may still read d_tab
+                    HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
+                    pc->tab_host = tab;
+                }
+                mm.T_tab = pc->d_tab;
+            } else {
+                mm.T = dts[0]->plain;
+            }
+            for (int k = 0; k < (counts[i] + 63) / 64; ++k, ++b) { h_piece[b] = i; h_first[b] = offsets[i] + 64 * k; }
+        }
+        hm[i] = mm;
+    }
+    HIP_TRY(hipMemcpyAsync(h->s_models.ptr, hm, b_models, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(hipMemcpyAsync(h->s_blk.ptr, h_end, b_ints, hipMemcpyHostToDevice, h->stream));
+    const int *d_end = (const int *)h->s_blk.ptr, *d_piece = d_end + np, *d_first = d_piece + blocks;
+    const pcx_bary *p0 = h->pieces[0];
+    const int *perm = (const int *)h->s_perm.ptr;
+    const SplinePieceModel *dm = (const SplinePieceModel *)h->s_models.ptr;
+    switch (d) {
+    case 1: rc = launch_small_pieces_d<0>(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream); break;
+    case 2: rc = launch_small_pieces_d<1>(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream); break;
+    case 3: rc = launch_small_pieces_d<2>(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream); break;
+    case 4: rc = launch_small_pieces_d<3>(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream); break;
+    default: return PCX_OK;
+    }
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    // the staging buffer is rewritten by the next chunk / call: its copies must have left the host
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *done = true;
+    return PCX_OK;
+}
+
 // One chunk of device-resident points through routing, bucketing and the per-piece launches, on h->stream
 // (results land in dout in point order; the launches are queued, not awaited).  Caller holds h->mu.
 static int spline_eval_chunk(pcx_spline *h, const double *dp, long cnt, const int32_t *derivs, int m, double *dout) {
@@ -1330,6 +1455,11 @@ static int spline_eval_chunk(pcx_spline *h, const double *dp, long cnt, const in
     std::vector<int> counts, offsets;
     int rc = spline_bucket(h, dp, cnt, counts, offsets);
     if (rc) return rc;
+    {
+        bool done = false;
+        rc = spline_launch_fused(h, dp, counts, offsets, derivs, m, dout, &done);
+        if (rc || done) return rc;
+    }
     const int *perm = (const int *)h->s_perm.ptr;
     int busy = 0;
     for (int i = 0; i < h->n_pieces; ++i) busy += counts[i] ? 1 : 0;

@@ -200,3 +200,24 @@ def test_spline_routing_without_lds_histograms(monkeypatch):
     assert np.array_equal(sp.eval_multi_batch(pts, case["specs"]), want)
     big = np.tile(pts, (40, 1))
     assert np.array_equal(sp.eval_batch(big, case["specs"][0]), np.tile(want[:, 0], 40))
+
+
+@pytest.mark.gpu
+def test_spline_one_launch_for_all_pieces_equals_launch_per_piece(monkeypatch):
+    """Pieces of equal shape on the lane-per-point kernel are evaluated in ONE launch (a device table of piece
+    models, a workgroup list per bucket); PCX_SPLINE_FUSED=0 keeps a launch per piece.  Same per-point
+    arithmetic: bit-identical results, single- and multi-spec, incl. a batch that leaves pieces empty."""
+    case = F.SPLINE_CASES["c"]
+    sp = _build(case)
+    rng = np.random.default_rng(23)
+    pts = np.column_stack([rng.uniform(lo, hi, 150_001) for lo, hi in case["domain"]])
+    some = pts.copy()
+    some[:, 0] = np.where(some[:, 0] > 100.0, 99.0, some[:, 0])          # the S > 100 pieces stay empty
+    fused = [sp.eval_batch(pts, case["specs"][0]), sp.eval_multi_batch(pts, case["specs"]),
+             sp.eval_batch(some, case["specs"][1]), sp.eval_batch(pts[:1], case["specs"][0])]
+    monkeypatch.setenv("PCX_SPLINE_FUSED", "0")
+    sp.to_device(0)                                                        # new handle, created under the override
+    per_piece = [sp.eval_batch(pts, case["specs"][0]), sp.eval_multi_batch(pts, case["specs"]),
+                 sp.eval_batch(some, case["specs"][1]), sp.eval_batch(pts[:1], case["specs"][0])]
+    for a, b in zip(fused, per_piece):
+        assert np.array_equal(a, b)
