@@ -405,3 +405,24 @@ def test_device_array_protocol_helpers_without_a_gpu():
     other = DeviceArray(1234, (7, 2), 1, owns=False)
     with pytest.raises(ValueError, match="device 1"):
         check_points(other, 2, 0)
+
+
+def test_rebuild_decision_follows_source_content_not_file_times(tmp_path, monkeypatch):
+    """_build.needs_build: a stamp with the digest of the sources next to the library decides; file times only
+    matter when there is no stamp (a copied checkout need not keep them)."""
+    from pychebyshev_amd import _build
+    lib = tmp_path / "libpcx_hip.so"
+    monkeypatch.setattr(_build, "LIB", str(lib))
+    monkeypatch.setattr(_build, "STAMP", str(lib) + ".stamp")
+    assert _build.needs_build()                                   # no library at all
+    lib.write_bytes(b"\x7fELF")
+    (tmp_path / "libpcx_hip.so.stamp").write_text(_build._source_digest() + "\n")
+    assert not _build.needs_build()
+    os.utime(lib, (1, 1))                                         # library "older" than every source: still current
+    assert not _build.needs_build()
+    (tmp_path / "libpcx_hip.so.stamp").write_text("0" * 64 + "\n")
+    assert _build.needs_build()                                   # other sources than the ones it was built from
+    (tmp_path / "libpcx_hip.so.stamp").unlink()
+    assert _build.needs_build()                                   # no stamp: file times decide (library from 1970)
+    digest = _build._source_digest()
+    assert len(digest) == 64 and digest == _build._source_digest()
