@@ -379,7 +379,7 @@ __device__ __forceinline__ void tt_w_gemm(const double *fk, int g, const double 
         const double tm = (g == 0) ? t4 : (g == 1) ? t3 : (g == 2) ? t2 : x;       // T_{4-g}
         const double c4 = 2.0 * t4;
         u[nt][0] = tg;
-        if (KS > 1) u[nt][1] = __builtin_fma(c4, tg, -tm);                          // T_{4+g}
+        if constexpr (KS > 1) u[nt][1] = __builtin_fma(c4, tg, -tm);                // T_{4+g}
 #pragma unroll
         for (int s = 2; s < KS; ++s) u[nt][s] = __builtin_fma(c4, u[nt][s - 1], -u[nt][s - 2]);
     }
