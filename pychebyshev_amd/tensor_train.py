@@ -583,22 +583,38 @@ class ChebyshevTT(ErgonomicsMixin):
                 if o not in (0, 1, 2):
                     raise ValueError(f"Derivative order {o} not supported (use 1 or 2)")
         out = np.empty((pts.shape[0], len(specs)))
+        if pts.shape[0] == 0:
+            return out
+        # stencil points per row: one dry traversal with scalars
+        n_stencil = [0]
+
+        def count(_q):
+            n_stencil[0] += 1
+            return 0.0
+        for spec in specs:
+            self._fd_spec([float(v) for v in pts[0, order]], spec, count)
         for start in range(0, pts.shape[0], max(1, int(chunk))):
             block = pts[start:start + chunk]
             n = block.shape[0]
             cols = [np.ascontiguousarray(block[:, order[k]]) for k in range(d)]       # storage frame
-            pending: list = []
+            # all stencil points of the block, written straight into the batch the device gets (user frame:
+            # storage dimension k is user column order[k])
+            batch = np.empty((n_stencil[0] * n, d))
+            filled = [0]
 
             def run(value_of):
                 return [self._fd_spec(cols, spec, value_of) for spec in specs]
 
             def record(q):
-                pending.append(np.column_stack([np.broadcast_to(c, (n,)) for c in q]))
+                lo = filled[0] * n
+                for k in range(d):
+                    batch[lo:lo + n, order[k]] = q[k]
+                filled[0] += 1
                 return 0.0
 
             run(record)                               # pass 1: collect the stencil columns
-            vals = self._eval_user_points(self._storage_to_user(np.concatenate(pending, axis=0)))
-            it = iter(np.split(vals, len(pending)))
+            vals = self._eval_user_points(batch)
+            it = iter(np.split(vals, n_stencil[0]))
             res = run(lambda q: next(it))             # pass 2: same traversal, real values
             for j, r in enumerate(res):
                 out[start:start + n, j] = r
