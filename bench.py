@@ -655,7 +655,16 @@ def run_rank(args) -> int:
     companions = {}
     if args.workload == "bary5d" and not args.no_companion:
         for name, field in (("greeks5d", "greeks"), ("tt5d", "tt"), ("tt10d", "tt10d")):
-            got = companion(name)
+            try:
+                got = companion(name)
+            except Exception as exc:                     # noqa: BLE001
+                # a companion must not take the headline line with it; with several ranks a failure in the
+                # middle of a gather cannot be contained, so there it still ends the run
+                if world > 1:
+                    raise
+                sys.stderr.write(f"bench.py: companion {name} failed: {type(exc).__name__}: {exc}\n")
+                companions[field] = {"error": f"{type(exc).__name__}: {exc}"}
+                continue
             if got is None:
                 continue
             out, cwl = got
