@@ -692,9 +692,13 @@ def run_rank(args) -> int:
                     out["per_spec_point_evals_per_s"] = per
                     out["specs"] = GREEK_SPECS
             if world == 1 and not args.no_cpu_baseline:
-                if name == "tt5d":
-                    out["cpu_baseline"] = cpu_baseline(cwl, 6.0)
-                out["end_to_end"] = end_to_end(cwl, reps=2)
+                try:
+                    if name == "tt5d":
+                        out["cpu_baseline"] = cpu_baseline(cwl, 6.0)
+                    out["end_to_end"] = end_to_end(cwl, reps=2)
+                except Exception as exc:                 # noqa: BLE001
+                    sys.stderr.write(f"bench.py: {name} baseline legs failed: {type(exc).__name__}: {exc}\n")
+                    out["baseline_error"] = f"{type(exc).__name__}: {exc}"
             companions[field] = out
 
     if rank == 0:
@@ -732,8 +736,15 @@ def run_rank(args) -> int:
                             "rccl_error": rccl_error, "torch": "torch" in sys.modules}
         line.update(companions)
     if world == 1 and not args.no_cpu_baseline:
-        e2e = end_to_end(wl)
-        cpu = cpu_baseline(wl, 10.0)
+        def guarded(what, fn):
+            # reported legs: a failure here (say, no C compiler for the oracle on this box) must not cost the line
+            try:
+                return fn()
+            except Exception as exc:                     # noqa: BLE001
+                sys.stderr.write(f"bench.py: {what} failed: {type(exc).__name__}: {exc}\n")
+                return {"error": f"{type(exc).__name__}: {exc}"}
+        e2e = guarded("end_to_end", lambda: end_to_end(wl))
+        cpu = guarded("cpu_baseline", lambda: cpu_baseline(wl, 10.0))
         if rank == 0:
             line["end_to_end"] = e2e
             line["cpu_baseline"] = cpu
