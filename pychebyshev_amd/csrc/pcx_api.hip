@@ -1093,8 +1093,11 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
                                (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
         return PCX_OK;
     };
-    for (int64_t start = 0; start < N; start += chunk, slot ^= 1) {
-        long cnt = (long)std::min<int64_t>(chunk, N - start);
+    // a short first piece (one round of workgroups) so that the first kernel starts after 2.6 MB instead of
+    // 10 MB of upload: nothing overlaps the first upload
+    const int64_t first_piece = (chunk == kPipeChunkPoints) ? (1 << 16) : chunk;
+    for (int64_t start = 0, step = first_piece; start < N; start += step, step = chunk, slot ^= 1) {
+        long cnt = (long)std::min<int64_t>(step, N - start);
         const bool second = (chunk == kPipeChunkPoints) && slot == 1;
         hipStream_t st = second ? h->stream2 : h->stream;
         Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
