@@ -182,7 +182,65 @@ def multi_case(rng, stats):
     return fails
 
 
-KINDS = {"bary": bary_case, "tt": tt_case, "spline": spline_case, "multi": multi_case}
+def slider_case(rng, stats):
+    """Random slider (2..6 dimensions, groups of 1..3, built through the Python callback): the device sum
+    against pivot + sum(oracle slide - pivot) in the reference's order, a single-slide derivative against the
+    oracle slide, a cross-slide mixed partial identically zero."""
+    from pychebyshev_amd import ChebyshevSlider
+    d = int(rng.integers(2, 7))
+    dims = [int(v) for v in rng.permutation(d)]
+    partition, i = [], 0
+    while i < d:
+        g = int(rng.integers(1, 4))
+        partition.append(sorted(dims[i:i + g]))
+        i += g
+    n = [int(rng.integers(3, 9)) for _ in range(d)]
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-3, 3, d), rng.uniform(0.5, 4, d))]
+    a = rng.uniform(0.3, 1.5, d)
+    c = rng.uniform(-0.2, 0.2, (d, d))
+
+    def f(x, _=None):
+        x = np.asarray(x, dtype=float)
+        return float(np.sum(np.sin(a * x)) + x @ c @ x * 0.1 + 2.0)
+
+    pivot = [float(rng.uniform(lo, hi)) for lo, hi in dom]
+    sl = ChebyshevSlider(f, d, dom, n, partition=partition, pivot_point=pivot)
+    sl.build(verbose=False)
+    npts = int(rng.choice([1, 63, 64, 65, 1000, 20000]))
+    pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+    models = [oracle.BaryModel(s_.nodes, s_.weights, s_.diff_matrices, s_.tensor_values) for s_ in sl.slides]
+    want = np.full(npts, float(sl.pivot_value))
+    for mdl, group in zip(models, sl.partition):
+        want += oracle.bary_eval_batch(mdl, np.ascontiguousarray(pts[:, list(group)]), [0] * len(group)) - sl.pivot_value
+    got = sl.eval_batch(pts, [0] * d)
+    scale = max(float(np.max(np.abs(want))), 1e-300)
+    fails = []
+    err = float(np.max(np.abs(got - want))) / scale if np.isfinite(got).all() else float("inf")
+    stats["slider_launches"] = stats.get("slider_launches", 0) + 1
+    stats["slider_worst"] = max(stats.get("slider_worst", 0.0), err)
+    if not err <= 1e-12:
+        fails.append(f"slider d={d} partition={partition} n={n} N={npts} value err={err:.3e}")
+    k = int(rng.integers(d))
+    gi = next(i for i, g in enumerate(sl.partition) if k in g)
+    spec = [0] * d
+    spec[k] = 1
+    sub = [1 if q == k else 0 for q in sl.partition[gi]]
+    wantd = oracle.bary_eval_batch(models[gi], np.ascontiguousarray(pts[:, list(sl.partition[gi])]), sub)
+    gotd = sl.eval_batch(pts, spec)
+    errd = float(np.max(np.abs(gotd - wantd))) / max(float(np.max(np.abs(wantd))), float(np.max(np.abs(want))), 1e-300)
+    stats["slider_worst"] = max(stats["slider_worst"], errd)
+    if not errd <= 1e-12:
+        fails.append(f"slider d={d} partition={partition} n={n} N={npts} spec={spec} err={errd:.3e}")
+    if len(sl.partition) > 1:
+        other = next(q for i, g in enumerate(sl.partition) if i != gi for q in g)
+        spec2 = list(spec)
+        spec2[other] = 1
+        if sl.eval_batch(pts, spec2).any():
+            fails.append(f"slider d={d} partition={partition}: cross-slide mixed partial {spec2} is not zero")
+    return fails
+
+
+KINDS = {"bary": bary_case, "tt": tt_case, "spline": spline_case, "multi": multi_case, "slider": slider_case}
 
 
 def main():
@@ -199,7 +257,7 @@ def main():
         seed = seed0 + cases
         rng = np.random.default_rng(seed)
         try:
-            kind = args.kind or ("bary", "tt", "bary", "tt", "spline", "multi")[cases % 6]
+            kind = args.kind or ("bary", "tt", "bary", "tt", "spline", "multi", "slider")[cases % 7]
             fails = KINDS[kind](rng, stats)
         except Exception as exc:                       # noqa: BLE001 -- an exception is a finding too
             fails = [f"exception {type(exc).__name__}: {exc}"]
@@ -216,7 +274,8 @@ def main():
     print(f"fuzz campaign: first seed {seed0}, {cases} cases, {stats['bary_launches']} barycentric, {stats['tt_launches']} TT and "
           f"{stats.get('spline_launches', 0)} spline evaluations against the oracle, {stats.get('multi_launches', 0)} multi-spec columns "
           f"against single-spec calls; worst error / scale: barycentric {stats['bary_worst']:.2e}, TT {stats['tt_worst']:.2e}, "
-          f"spline {stats.get('spline_worst', 0.0):.2e}, multi-spec {stats.get('multi_worst', 0.0):.2e} (bar 1e-12); "
+          f"spline {stats.get('spline_worst', 0.0):.2e}, multi-spec {stats.get('multi_worst', 0.0):.2e}, "
+          f"slider {stats.get('slider_worst', 0.0):.2e} over {stats.get('slider_launches', 0)} sliders (bar 1e-12); "
           f"failures: {len(failures)}")
     return 1 if failures else 0
 
