@@ -226,7 +226,7 @@ class TTWork(Workload):
                 str(list(built.tt_ranks)).replace(" ", ""), f"{n_points:,}")
             self.flop_per_eval = 2.0 * sum((11 + 1) * a * b for a, b in zip(built.tt_ranks[:-1], built.tt_ranks[1:]))
             self.bytes_per_eval = 48.0
-            self.kernel = "k_tt_eval_d4<2>"
+            self.kernel = "k_tt_eval_lpp<8,11>"     # lane-per-point v_fma_f64 form (FP64 vector peak = matrix peak)
         else:
             rng = np.random.default_rng(16)
             ranks = [1] + [16] * 9 + [1]

@@ -209,8 +209,10 @@ int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, double *d_o
 int pcx_tt_stream(pcx_tt *h, void **stream);
 /* Kernel selection: 0 = auto, 1 = direct form on v_mfma_f64_16x16x4 (one GEMM over (node, left
  * rank) per dimension; ranks <= 64), 2 = small-rank "W first" form (ranks <= 12, cores in LDS),
- * 3 = small-rank direct form on v_mfma_f64_4x4x4_4b (ranks <= 12, n <= 16, cores in LDS; what
- * auto picks when it applies).  PCX_ERR_UNSUPPORTED when the model is outside a form's range.
+ * 3 = small-rank direct form on v_mfma_f64_4x4x4_4b (ranks <= 12, n <= 16, cores in LDS),
+ * 4 = lane-per-point VALU form (ranks <= 16, n <= 16: one point per lane, core elements as scalar
+ * operands of v_fma_f64; what auto picks for ranks <= 15 since round 3).
+ * PCX_ERR_UNSUPPORTED when the model is outside a form's range.
  * Models with a rank above 64 always run on a generic wave-per-point kernel.            */
 int pcx_tt_set_kernel(pcx_tt *h, int variant);
 

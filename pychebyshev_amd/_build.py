@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libpcx_hip.so")
 # translation unit -> headers it includes (an object is rebuilt when any of them is newer)
 PCX_H = os.path.join("..", "..", "include", "pcx.h")
 SOURCES = {
-    "pcx_api.hip": ["pcx_common.h", "bary_kernels.h", "tt_kernels.h", "ttcross_kernels.h", "ttsvd_kernels.h",
+    "pcx_api.hip": ["pcx_common.h", "bary_kernels.h", "tt_kernels.h", "tt_lpp_kernels.h", "ttcross_kernels.h", "ttsvd_kernels.h",
                     PCX_H],
     "pcx_comm.hip": [PCX_H],
 }

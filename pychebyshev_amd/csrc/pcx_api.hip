@@ -16,6 +16,7 @@
 
 #include "bary_kernels.h"
 #include "tt_kernels.h"
+#include "tt_lpp_kernels.h"
 #include "ttcross_kernels.h"
 #include "ttsvd_kernels.h"
 
@@ -1811,7 +1812,13 @@ struct pcx_tt {
     TTD4Plan d4plan;
     long d4_resident = 0;
     double *d_img4 = nullptr;
-    int variant = 0;      // 0 auto, 1 direct form (16x16x4), 2 W-first form, 3 direct form (4x4x4)
+    // lane-per-point VALU form (tt_lpp_kernels.h; ranks <= 16, n <= 16): exact image [b][a][j] + per-dim table
+    int lppCap = 0;       // 0 = not available, else the instantiation's rank cap: 8 or 16
+    int lpp_nodes = 0;    // the node count every dimension shares (instantiations with one switch level), 0 = they differ
+    bool lpp_preferred = false;  // auto takes it (ranks <= 15: measured ahead of every MFMA form, profiles/r03_tt_rate_probe.txt)
+    double *d_lpp_img = nullptr;
+    TTLppDim *d_lpp_tab = nullptr;
+    int variant = 0;      // 0 auto, 1 direct form (16x16x4), 2 W-first form, 3 direct form (4x4x4), 4 lane per point
     bool generic = false; // ranks > 64: wave-per-point kernel on the plain cores
     TTGeneric gi;
     double *d_cores = nullptr;
@@ -1828,6 +1835,8 @@ extern "C" int pcx_tt_destroy(pcx_tt *h) {
     (void)hipFree(h->d_last);
     (void)hipFree(h->d_img);
     (void)hipFree(h->d_img4);
+    (void)hipFree(h->d_lpp_img);
+    (void)hipFree(h->d_lpp_tab);
     (void)hipFree(h->d_cores);
     h->s_pts.release(); h->s_out.release();
     h->pin.release();
@@ -2038,6 +2047,31 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
             }
         }
     }
+    // lane-per-point image (tt_lpp_kernels.h): img[off_k + (b rl + a) n + j] = G_k[a][j][b], nothing padded;
+    // 64 zeroed doubles behind the end (scalar loads are merged into 64-byte reads).
+    if (h->rmax <= PCX_LPP_MAX_RANK && nmax <= PCX_LPP_MAX_NODES) {
+        std::vector<TTLppDim> tab(d);
+        std::vector<double> img((size_t)core_total + 64, 0.0);
+        for (int k = 0; k < d; ++k) {
+            const int rl = ranks[k], rr = ranks[k + 1], nk = n_nodes[k];
+            tab[k] = TTLppDim{(int)coff[k], rl, rr, nk, h->dims.col[k], 0, lo[k], h->dims.scale[k]};
+            double *dst = img.data() + coff[k];
+            const double *G = cores_cat + coff[k];
+            for (int b = 0; b < rr; ++b)
+                for (int a = 0; a < rl; ++a)
+                    for (int j = 0; j < nk; ++j) dst[((size_t)b * rl + a) * nk + j] = G[((size_t)a * nk + j) * rr + b];
+        }
+        if (hipMalloc((void **)&h->d_lpp_img, img.size() * sizeof(double)) == hipSuccess &&
+            hipMalloc((void **)&h->d_lpp_tab, tab.size() * sizeof(TTLppDim)) == hipSuccess &&
+            hipMemcpy(h->d_lpp_img, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
+            hipMemcpy(h->d_lpp_tab, tab.data(), tab.size() * sizeof(TTLppDim), hipMemcpyHostToDevice) == hipSuccess) {
+            h->lppCap = h->rmax <= 8 ? 8 : 16;
+            h->lpp_nodes = n_nodes[0];
+            for (int k = 1; k < d; ++k)
+                if (n_nodes[k] != n_nodes[0]) h->lpp_nodes = 0;
+            h->lpp_preferred = h->rmax <= 15;       // rank 16: the 16x16x4 direct form is ahead (0.70-0.79 vs 0.66-0.69)
+        }
+    }
     hipError_t e1 = hipGetLastError();
     hipError_t e2 = hipStreamSynchronize(h->stream);
     (void)hipFree(d_cores);
@@ -2123,6 +2157,29 @@ static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipS
     }
     if (h->variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
     if (h->variant == 3 && !h->d4RA) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 direct TT kernel does not cover this model");
+    if (h->variant == 4 && !h->lppCap) return fail(PCX_ERR_UNSUPPORTED, "lane-per-point TT kernel does not cover this model");
+    if (h->lppCap && (h->variant == 4 || (h->variant == 0 && h->lpp_preferred))) {
+        const long blocks = (N + PCX_LPP_WG - 1) / PCX_LPP_WG;
+        if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+        const size_t lds = (size_t)h->rmax * PCX_LPP_WG * sizeof(double);
+#define PCX_LPP_GO(RCAP, NJ)                                                                                        \
+        hipLaunchKernelGGL((k_tt_eval_lpp<RCAP, NJ>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), lds, st, h->d_lpp_tab, \
+                           h->dims.d, h->d_lpp_img, d_pts, d_out, N)
+#define PCX_LPP_GO_N(RCAP)                                                                                           \
+        switch (h->lpp_nodes) {                                                                                      \
+        case 1: PCX_LPP_GO(RCAP, 1); break; case 2: PCX_LPP_GO(RCAP, 2); break; case 3: PCX_LPP_GO(RCAP, 3); break;  \
+        case 4: PCX_LPP_GO(RCAP, 4); break; case 5: PCX_LPP_GO(RCAP, 5); break; case 6: PCX_LPP_GO(RCAP, 6); break;  \
+        case 7: PCX_LPP_GO(RCAP, 7); break; case 8: PCX_LPP_GO(RCAP, 8); break; case 9: PCX_LPP_GO(RCAP, 9); break;  \
+        case 10: PCX_LPP_GO(RCAP, 10); break; case 11: PCX_LPP_GO(RCAP, 11); break; case 12: PCX_LPP_GO(RCAP, 12); break; \
+        case 13: PCX_LPP_GO(RCAP, 13); break; case 14: PCX_LPP_GO(RCAP, 14); break; case 15: PCX_LPP_GO(RCAP, 15); break; \
+        case 16: PCX_LPP_GO(RCAP, 16); break; default: PCX_LPP_GO(RCAP, 0); break;                                   \
+        }
+        if (h->lppCap == 8) { PCX_LPP_GO_N(8) } else { PCX_LPP_GO_N(16) }
+#undef PCX_LPP_GO_N
+#undef PCX_LPP_GO
+        HIP_TRY(hipGetLastError());
+        return PCX_OK;
+    }
     if (h->d4RA && (h->variant == 3 || (h->variant == 0 && (!h->wR || h->d4_preferred)))) {
         if (h->d4RA == 1) return tt_launch_d4<1>(h, d_pts, N, d_out, st);
         if (h->d4RA == 2) return tt_launch_d4<2>(h, d_pts, N, d_out, st);
@@ -2159,6 +2216,7 @@ extern "C" int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, 
     if (N < 0) return fail(PCX_ERR_INVALID, "N < 0");
     if (N > 0 && (!d_pts || !d_out)) return fail(PCX_ERR_INVALID, "NULL device buffer");
     HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);      // tt_launch reads h->variant and fills the lazy residency counts
     return tt_launch(h, d_pts, (long)N, d_out, stream ? (hipStream_t)stream : h->stream);
 }
 
@@ -2195,10 +2253,12 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
 
 extern "C" int pcx_tt_set_kernel(pcx_tt *h, int variant) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
-    if (variant < 0 || variant > 3) return fail(PCX_ERR_INVALID, "variant %d outside [0, 3]", variant);
+    if (variant < 0 || variant > 4) return fail(PCX_ERR_INVALID, "variant %d outside [0, 4]", variant);
     if (variant == 2 && !h->wR) return fail(PCX_ERR_UNSUPPORTED, "W-first TT kernel does not cover this model");
     if (variant == 3 && !h->d4RA) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 direct TT kernel does not cover this model");
+    if (variant == 4 && !h->lppCap) return fail(PCX_ERR_UNSUPPORTED, "lane-per-point TT kernel does not cover this model");
     if (variant != 0 && h->generic) return fail(PCX_ERR_UNSUPPORTED, "ranks above 64 run on the generic kernel only");
+    std::lock_guard<std::mutex> lk(h->mu);
     h->variant = variant;
     return PCX_OK;
 }

@@ -72,19 +72,20 @@ def _set_tt_kernel(tt, variant):
 
 
 def test_all_tt_kernel_forms_agree_with_reference():
-    """Ranks <= 12 have three kernels: the direct (node, rank)-GEMM form on the 16x16x4 MFMA (1),
-    the small-rank "W first" form (2) and the small-rank direct form on the 4x4x4 MFMA (3, what
-    auto picks for n <= 16).  All must match the reference."""
+    """Ranks <= 12 have four kernels: the direct (node, rank)-GEMM form on the 16x16x4 MFMA (1),
+    the small-rank "W first" form (2), the small-rank direct form on the 4x4x4 MFMA (3) and the
+    lane-per-point VALU form (4, ranks <= 16, n <= 16; what auto picks for ranks <= 12 since round 3).
+    All must match the reference."""
     g = golden("g4_tt_bs5d")
     for mr in (8, 15):
         tt = ChebyshevTT.from_coeff_cores(_cores(g, f"r{mr}_", 5), F.BS5_DOMAIN)
-        for variant in (1, 2, 3, 0):
+        for variant in (1, 2, 3, 4, 0):
             _set_tt_kernel(tt, variant)
             assert_parity(tt.eval_batch(g["points"]), g[f"r{mr}_eval"], 1e-12, f"TT r{mr} variant {variant}")
     g = golden("g5b_tt_mixed")
     dom = [[0.0, 2.0], [-3.0, -1.0], [10.0, 11.0], [-1.0, 1.0]]
     tt = ChebyshevTT.from_coeff_cores(_cores(g, "", 4), dom)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         _set_tt_kernel(tt, variant)
         assert_parity(tt.eval_batch(g["points"]), g["out"], 1e-12, f"mixed variant {variant}")
     g = golden("g5_tt_rank16")
@@ -92,7 +93,10 @@ def test_all_tt_kernel_forms_agree_with_reference():
     t = tt16._dev()
     assert t.lib.pcx_tt_set_kernel(t.handle, 2) == _lib.PCX_ERR_UNSUPPORTED     # rank 16 > 12
     assert t.lib.pcx_tt_set_kernel(t.handle, 3) == _lib.PCX_ERR_UNSUPPORTED
-    assert t.lib.pcx_tt_set_kernel(t.handle, 4) == _lib.PCX_ERR_INVALID
+    assert t.lib.pcx_tt_set_kernel(t.handle, 5) == _lib.PCX_ERR_INVALID
+    for variant in (4, 0):                                                      # rank 16: lane-per-point covers it, auto keeps the MFMA form
+        _set_tt_kernel(tt16, variant)
+        assert_parity(tt16.eval_batch(g["points"]), g["out"], 1e-12, f"rank 16 variant {variant}")
 
 
 def test_small_rank_forms_over_rank_classes_node_counts_and_batch_tails(oracle_mod):
@@ -114,7 +118,7 @@ def test_small_rank_forms_over_rank_classes_node_counts_and_batch_tails(oracle_m
                 pts[:, order[k]] = rng.uniform(dom[k][0], dom[k][1], npts)
             ref = oracle_mod.tt_eval_batch(cores, dom, pts, dim_order=order)
             scale = max(float(np.max(np.abs(ref))), 1e-300)
-            for variant in (3, 2):
+            for variant in (4, 3, 2):
                 _set_tt_kernel(tt, variant)
                 got = tt.eval_batch(pts)
                 assert np.max(np.abs(got - ref)) <= 1e-12 * scale, (d, n, ranks, npts, variant)
@@ -331,7 +335,7 @@ def test_points_outside_the_domain_extrapolate_like_the_reference_algorithm(orac
     rng = np.random.default_rng(3)
     pts = lo + (hi - lo) * rng.uniform(-0.1, 1.1, (500, 5))
     ref = oracle_mod.tt_eval_batch(cores, F.BS5_DOMAIN, pts)
-    for variant in (1, 2, 3):
+    for variant in (1, 2, 3, 4):
         _set_tt_kernel(tt, variant)
         y = tt.eval_batch(pts)
         assert np.max(np.abs(y - ref)) <= 1e-11 * np.max(np.abs(ref)), variant

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Device-resident eval_batch throughput of synthetic TT models over rank classes / shapes
-(ranks <= 12: the 4x4x4 direct kernel (n <= 16) or the W-first kernel; ranks 13..64: the 16x16x4 direct kernel).
+(every form forced where it applies: lane-per-point VALU (ranks <= 16, n <= 16), the 4x4x4 direct kernel (ranks <= 12,
+n <= 16), the W-first kernel (ranks <= 12), the 16x16x4 direct kernel (ranks <= 64)).
 
     python tools/tt_rate_probe.py [--points 4000000]
 """
@@ -55,11 +56,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=4_000_000)
     a = ap.parse_args()
-    print(f"{'d':>3} {'rank':>4} {'n':>3}  {'auto pts/s':>12} {'frac':>6}   {'d4x4 pts/s':>12} {'frac':>6}   {'W-first pts/s':>13} {'frac':>6}"
-          f"   {'direct16 pts/s':>14} {'frac':>6}")
-    for d, r, n in [(5, 2, 11), (5, 4, 11), (10, 4, 11), (5, 8, 11), (5, 8, 16), (5, 8, 20), (5, 12, 11), (10, 12, 11),
-                    (5, 16, 11), (10, 16, 11), (5, 32, 11), (5, 64, 11)]:
-        res = [rate(d, r, n, a.points, variant=v) for v in (0, 3, 2, 1)]
+    print(f"{'d':>3} {'rank':>4} {'n':>3}  {'auto pts/s':>12} {'frac':>6}   {'lane/pt pts/s':>13} {'frac':>6}   {'d4x4 pts/s':>12} {'frac':>6}   "
+          f"{'W-first pts/s':>13} {'frac':>6}   {'direct16 pts/s':>14} {'frac':>6}")
+    for d, r, n in [(5, 2, 11), (5, 3, 7), (5, 4, 11), (10, 4, 11), (5, 6, 9), (5, 8, 11), (5, 8, 16), (5, 8, 20), (5, 10, 11),
+                    (5, 12, 11), (10, 12, 11), (5, 13, 11), (5, 14, 11), (5, 16, 11), (10, 16, 11), (5, 16, 16), (5, 32, 11),
+                    (5, 64, 11)]:
+        res = [rate(d, r, n, a.points, variant=v) for v in (0, 4, 3, 2, 1)]
         print(f"{d:>3} {r:>4} {n:>3}  " + "   ".join(f"{x[0]:13.4e} {x[1]:6.3f}" for x in res))
 
 
