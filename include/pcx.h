@@ -144,6 +144,14 @@ int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const do
  * PCX_ERR_UNSUPPORTED when the shape is not covered.  info_out receives
  * {variant used by auto, row tiles, k-steps, lds bytes, points per workgroup, split}.  */
 int pcx_bary_set_kernel(pcx_bary *h, int variant);
+/* Multi-spec batches (pcx_bary_eval_multi_batch[_dev], N >= 65,536 on the MFMA kernel): specs that differ only in
+ * their derivative order along dimension 0 by at most `span` share ONE contraction of dimensions 1 .. d-1 and are
+ * finished with D_0 on the per-node partial sums -- the order of operations of the reference's
+ * vectorized_eval_multi (barycentric.py:1098-1110).  span = 1 (default; PCX_BARY_G0_SPAN overrides it at load):
+ * price and delta share a GEMM, within 2e-13 of the reference's batch results on 5-D Black-Scholes; span = 2 also
+ * folds gamma in (one GEMM less, gamma then 4e-12 from the reference's batch path: each D_0 applied after the
+ * contraction amplifies the rounding of the partial sums); span = 0: every spec gets its own GEMM.            */
+int pcx_bary_set_group_span(pcx_bary *h, int span);
 int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
 int pcx_bary_stream(pcx_bary *h, void **stream);
 

@@ -1,43 +1,54 @@
-"""Derivative-spec bookkeeping shared by the interpolant classes: ``get_derivative_id`` and the
-"orders xor id" resolution of every evaluation method (reference barycentric.py:1173-1243,
-spline.py:447-517, slider.py:201-245 -- three identical copies there)."""
+"""Derivative-spec bookkeeping shared by the interpolant classes (one module here; the reference keeps a
+copy per class: barycentric.py:1173-1243, spline.py:447-517, slider.py:201-245).
+
+Contract kept from the reference: ids are sequential from 0 in registration order and stable per orders
+tuple; the messages of the ``ValueError`` / ``KeyError`` cases below.  Everything else -- one validation
+helper that yields the canonical key, ``dict.setdefault`` as the registry, a two-flag dispatch for the
+"orders xor id" rule -- is this package's own shape."""
 from __future__ import annotations
 
 import numpy as np
 
 
+def canonical_orders(orders, ndim: int, max_order: int) -> tuple:
+    """The orders as a tuple of Python ints, or ``ValueError`` naming the first offending entry."""
+    if len(orders) != ndim:
+        raise ValueError(f"derivative_order length {len(orders)} does not match num_dimensions {ndim}")
+
+    def entry(axis, value):
+        if not isinstance(value, (int, np.integer)):            # as in the reference, bool counts as int
+            raise ValueError(f"derivative_order[{axis}] must be int, got {type(value).__name__}")
+        if not 0 <= value <= max_order:
+            raise ValueError(f"derivative_order[{axis}]={value} out of range [0, {max_order}]")
+        return int(value)
+
+    return tuple(entry(axis, value) for axis, value in enumerate(orders))
+
+
 class DerivativeIdMixin:
-    """Needs ``num_dimensions``, ``max_derivative_order``, ``_derivative_id_registry`` (dict)
-    and ``_derivative_id_to_orders`` (list) on the host class."""
+    """Needs ``num_dimensions``, ``max_derivative_order``, ``_derivative_id_registry`` (dict: orders ->
+    id) and ``_derivative_id_to_orders`` (list: id -> orders) on the host class."""
 
     def get_derivative_id(self, derivative_order) -> int:
-        """Register a per-dimension derivative-orders tuple; stable, sequential ids from 0."""
-        if len(derivative_order) != self.num_dimensions:
-            raise ValueError(f"derivative_order length {len(derivative_order)} does not "
-                             f"match num_dimensions {self.num_dimensions}")
-        for d, o in enumerate(derivative_order):
-            if not isinstance(o, (int, np.integer)):
-                raise ValueError(f"derivative_order[{d}] must be int, got {type(o).__name__}")
-            if o < 0 or o > self.max_derivative_order:
-                raise ValueError(f"derivative_order[{d}]={o} out of range [0, {self.max_derivative_order}]")
-        key = tuple(int(o) for o in derivative_order)
-        found = self._derivative_id_registry.get(key)
-        if found is not None:
-            return found
-        new_id = len(self._derivative_id_to_orders)
-        self._derivative_id_registry[key] = new_id
-        self._derivative_id_to_orders.append(key)
-        return new_id
+        """Register a per-dimension derivative-orders tuple; the same tuple always maps to the same id."""
+        orders = canonical_orders(derivative_order, self.num_dimensions, self.max_derivative_order)
+        table = self._derivative_id_to_orders
+        ident = self._derivative_id_registry.setdefault(orders, len(table))
+        if ident == len(table):                   # first sighting: the id just handed out is the next slot
+            table.append(orders)
+        return ident
 
     def _resolve_derivative_args(self, derivative_order, derivative_id):
-        """Exactly one of orders / id: ``ValueError`` for both or neither, ``KeyError`` for an
-        unknown id."""
-        if derivative_order is not None and derivative_id is not None:
+        """Exactly one of orders / id: ``ValueError`` for both or neither, ``KeyError`` for an id that
+        was never registered.  Orders pass through untouched (range-checked where they are used)."""
+        given = (derivative_order is not None, derivative_id is not None)
+        if given == (True, True):
             raise ValueError("provide exactly one of derivative_order or derivative_id, not both")
-        if derivative_order is None and derivative_id is None:
+        if given == (False, False):
             raise ValueError("must provide derivative_order or derivative_id")
-        if derivative_id is not None:
-            if derivative_id < 0 or derivative_id >= len(self._derivative_id_to_orders):
-                raise KeyError(f"unknown derivative_id {derivative_id}; register via get_derivative_id() first")
-            return list(self._derivative_id_to_orders[derivative_id])
-        return derivative_order
+        if given[0]:
+            return derivative_order
+        table = self._derivative_id_to_orders
+        if not 0 <= derivative_id < len(table):
+            raise KeyError(f"unknown derivative_id {derivative_id}; register via get_derivative_id() first")
+        return list(table[derivative_id])

@@ -69,6 +69,49 @@ __global__ void k_pack_fragments(const double *__restrict__ T2, double *__restri
     frag[idx] = (m < M && k < K) ? T2[(long)m * K + k] : 0.0;
 }
 
+// Slab packing for dim-0 groups (BaryG0): the tensor viewed as (n0 x M1 x K); slab i0 is packed like a
+// tensor of its own into `tps` row tiles (M1 rows padded to 16 tps), so no row tile straddles two i0.
+__global__ void k_pack_fragments_slabs(const double *__restrict__ T3, double *__restrict__ frag, int n0, int M1,
+                                       int K, int tps, int KS) {
+    long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long per_slab = (long)tps * KS * 64;
+    if (idx >= per_slab * n0) return;
+    const int i0 = (int)(idx / per_slab);
+    const long r = idx - (long)i0 * per_slab;
+    int l = (int)(r & 63);
+    long ts = r >> 6;
+    int s = (int)(ts % KS);
+    int t = (int)(ts / KS);
+    int m = 16 * t + (l & 15);
+    int k = 4 * s + (l >> 4);
+    frag[idx] = (m < M1 && k < K) ? T3[((long)i0 * M1 + m) * K + k] : 0.0;
+}
+
+// Finish of a dim-0 group for ONE point: vec (n0 entries at vecA[i * stride]) holds the per-i0 partial sums P;
+// for o = 0 .. maxorder: y_o = sum_i b0[i] (D_0^o P)[i], written to the columns of the members with order o.
+// D_0 is wave-uniform (scalar loads); one j-ascending fma chain per entry, like k_mode_product.
+__device__ __forceinline__ void bary_g0_finish(const BaryG0 &gs, const double *__restrict__ diff0, double *vecA,
+                                               double *vecB, const double *b0, int stride, double *out_row) {
+    typedef const double __attribute__((address_space(4))) *cptr_t;
+    const cptr_t D0 = (cptr_t)(unsigned long long)diff0;
+    const int n0 = gs.n0;
+    for (int o = 0; o <= gs.maxorder; ++o) {
+        if (o > 0) {
+            for (int i = 0; i < n0; ++i) {
+                double s = 0.0;
+                for (int j = 0; j < n0; ++j) s = __builtin_fma(vecA[j * stride], D0[i * n0 + j], s);
+                vecB[i * stride] = s;
+            }
+            double *t = vecA; vecA = vecB; vecB = t;
+        }
+        double y = 0.0;
+        for (int i = 0; i < n0; ++i) y = __builtin_fma(b0[i * stride], vecA[i * stride], y);
+        if (out_row)
+            for (int s = 0; s < gs.nmem; ++s)
+                if (gs.order[s] == o) out_row[gs.col[s]] = y;
+    }
+}
+
 // ---------------------------------------------------------------------------------
 // K1: normalised barycentric weights of one coordinate for one dimension
 // (reference barycentric.py:1039-1045 / :1083-1094): first node with |x - node| < 1e-14
@@ -156,7 +199,11 @@ __device__ __forceinline__ double code_weight_t(unsigned code, const double *bw_
 
 // WIDE: more than four head or tail dimensions (d up to 16): every code has a second word
 // (rowcode_hi / kcode_hi, fields 4..7) and a weight is the product of both words' products.
-template <int KS, int NT, bool WIDE, int NF = 4>
+// G0: dim-0 group launch (BaryG0, pcx_common.h): the fragment image is slab-packed (plan.MT = n0 * tps row tiles),
+// the row codes name the head dimensions 1 .. split-1 only, at the end of every slab the wave's partial sum
+// P[i0] is reduced over the four lane groups into the (by then dead) tail part of its LDS table, and the
+// epilogue finishes all members of the group from P (bary_g0_finish).  grid.y = grid.z = 1.
+template <int KS, int NT, bool WIDE, int NF = 4, bool G0 = false>
 __global__ void __launch_bounds__(256, 2)
 k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             const double *__restrict__ wts, const double *const *__restrict__ frag_tab,
@@ -164,7 +211,7 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
             const unsigned *__restrict__ rowcode_hi, const unsigned *__restrict__ kcode_hi,
             const double *__restrict__ pts, double *__restrict__ out, long N, long ostride,
             long ooff, int chunks_per_split, double *__restrict__ partial,
-            const int *__restrict__ perm) {
+            const int *__restrict__ perm, BaryG0 gs, const double *__restrict__ diff0) {
     // perm (optional): the launch covers the N rows perm[0..N) of pts/out (a bucket of a
     // piecewise interpolant) instead of rows 0..N.
     static_assert(NT == 1 || NT == 2 || NT == 4, "PW must divide the wave");
@@ -349,6 +396,21 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) cs[nt] = __builtin_fma(acc[nt][j], w[nt][j], cs[nt]);
+        if constexpr (G0) {
+            if ((t + 1) % gs.tps == 0) {            // end of slab i0: P[i0] = (s0 + s1) + (s2 + s3) -> LDS
+                const int i0 = t / gs.tps;
+                double *Pl = const_cast<double *>(bwt);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    double v = cs[nt];
+                    v += __shfl_xor(v, 16, 64);
+                    v += __shfl_xor(v, 32, 64);
+                    if (g == 0) Pl[(size_t)i0 * PW + 16 * nt + c] = v;
+                    cs[nt] = 0.0;
+                }
+            }
+            continue;
+        }
         const bool chunk_end = ((t + 1) % PCX_CHUNK_TILES == 0) || (t + 1 == plan.MT);
         if (chunk_end) {
             if (split) {
@@ -365,6 +427,17 @@ k_bary_mfma(BaryDims dims, BaryMfmaPlan plan, const double *__restrict__ nodes,
         }
     }
 
+    if constexpr (G0) {
+        // one lane per point finishes the group from P (wave-private LDS: a wave's LDS operations are in order)
+        if (lane < PW) {
+            double *Pl = const_cast<double *>(bwt) + lane;
+            const long pidx = base + lane;
+            const long row = (pidx < N) ? (perm ? (long)perm[pidx] : pidx) : 0;
+            bary_g0_finish(gs, diff0, Pl, Pl + (size_t)gs.n0 * PW, bw + (size_t)dims.off[0] * PW + lane, PW,
+                           pidx < N ? out + row * ostride + ooff : nullptr);
+        }
+        return;
+    }
     // ---- add the four 16-lane groups: lane group 0 ends with (s0 + s1) + (s2 + s3)
     if (!split) {
 #pragma unroll

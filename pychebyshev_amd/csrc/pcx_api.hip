@@ -272,13 +272,17 @@ struct DerivedTensor {
     double *plain = nullptr;  // C-order tensor after the derivative passes (prod n doubles)
     double *frag = nullptr;   // MFMA A-fragment packing of `plain` (MT*KS*64 doubles) or NULL
     double **slot = nullptr;  // device table with the single entry `frag` (kernel's frag_tab)
+    double *frag_g0 = nullptr;   // slab packing for dim-0 group launches (n0 * tps * KS * 64 doubles), built on first use
+    double **slot_g0 = nullptr;  // device table with the single entry `frag_g0`
     uint64_t last_use = 0;    // handle clock at the last request (least-recently-used eviction)
     void free_all() {
         if (plain) (void)hipFree(plain);
         if (frag) (void)hipFree(frag);
         if (slot) (void)hipFree(slot);
-        plain = frag = nullptr;
-        slot = nullptr;
+        if (frag_g0) (void)hipFree(frag_g0);
+        if (slot_g0) (void)hipFree(slot_g0);
+        plain = frag = frag_g0 = nullptr;
+        slot = slot_g0 = nullptr;
     }
 };
 
@@ -296,6 +300,12 @@ struct pcx_bary {
     unsigned *d_rowcode = nullptr, *d_kcode = nullptr;
     unsigned *d_rowcode_hi = nullptr, *d_kcode_hi = nullptr;   // fields 4..7 (wide plans only)
     bool wide = false;      // more than four head or tail dimensions
+    // dim-0 groups (BaryG0): specs differing only in their dim-0 order share one slab-packed GEMM
+    bool g0_ok = false;
+    int g0_tps = 0;                  // row tiles per dim-0 slab
+    int g0_nf = 2;                   // live row-code fields (head dimensions 1 .. split-1, at least two)
+    unsigned *d_rowcode_g0 = nullptr;
+    int g0_span = 1;                 // dim-0 orders above its base tensor's a slab GEMM serves (pcx_bary_set_group_span)
     int lpp = 64;                    // lanes per point in the rows kernel
     bool mfma4_ok = false;           // 4x4x4_4b form available (LDS budget)
     int small_nlp = 0;               // lane-per-point kernel for small tensors: padded last-dim width, 0 = not available
@@ -316,6 +326,14 @@ struct pcx_bary {
     Scratch s_partial;               // per-chunk totals of split launches
     Pinned pin;                      // zero-copy staging for small host-pointer batches
 };
+
+// How many dim-0 orders above its base tensor's a slab GEMM serves.  Differentiating AFTER the contraction (as the
+// reference's vectorized_eval_multi does) rounds differently from the reference's batch path, which differentiates the
+// tensor first: each D_0 applied to the partial sums amplifies their rounding by ~|D_0| |P| / |result|.  One level keeps
+// 5-D Black-Scholes delta / vanna within 2e-13 of the reference's batch result; two levels put gamma at 4.4e-12 --
+// outside the 1e-12 bar -- so the default is 1 (price + delta share a GEMM, gamma keeps its own);
+// PCX_BARY_G0_SPAN=2 trades that for one GEMM less, 0 switches the grouping off.
+static const int g_g0_span_default = [] { const char *e = getenv("PCX_BARY_G0_SPAN"); return e ? std::min(8, std::max(0, atoi(e))) : 1; }();
 
 static const long kSmallTensorElems = 4096;   // auto: tensors up to this size run on k_bary_small
 static const int kMaxSpecs = 64;      // derivative specs evaluated by one launch (grid.z)
@@ -382,6 +400,7 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     (void)hipFree(h->d_snodes);
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
     (void)hipFree(h->d_rowcode_hi); (void)hipFree(h->d_kcode_hi);
+    (void)hipFree(h->d_rowcode_g0);
     h->s_pts.release(); h->s_out.release();
     h->s_pts2.release(); h->s_out2.release();
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
@@ -424,6 +443,7 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     if (!h) return fail(PCX_ERR_NOMEM, "out of host memory");
     h->device = device;
     h->dims.d = d;
+    h->g0_span = g_g0_span_default;
     long total = 1, sum_n = 0, sum_n2 = 0;
     for (int k = 0; k < d; ++k) {
         if (n_nodes[k] < 1 || n_nodes[k] > 4096) { delete h; return fail(PCX_ERR_INVALID, "n_nodes[%d]=%d outside [1, 4096]", k, n_nodes[k]); }
@@ -564,6 +584,44 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
         CREATE_TRY(hipMalloc((void **)&h->d_kcode, kcode.size() * sizeof(unsigned)));
         CREATE_TRY(hipMemcpy(h->d_rowcode, rowcode.data(), rowcode.size() * sizeof(unsigned), hipMemcpyHostToDevice));
         CREATE_TRY(hipMemcpy(h->d_kcode, kcode.data(), kcode.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        // dim-0 groups: head = dimension 0 x (dimensions 1 .. split-1); the rows of one i0 form a slab padded to whole
+        // tiles.  Needs two column tiles per wave (large batches only), narrow codes, and room for two n0-vectors
+        // per point in the tail part of the LDS table (dead once the B operands are in registers); n0 <= 16 bounds the
+        // rounding amplification of the D_0 step (~ n0^2 eps).
+        long M1 = 1;
+        for (int k = 1; k < p.split; ++k) M1 *= h->dims.n[k];
+        if (!h->wide && p.split >= 2 && p.split <= PCX_CODE_FIELDS && h->nt == 2 && p.KS <= 32 && M1 >= 16 &&
+            2 * h->dims.n[0] <= p.rows - p.tail_base && h->dims.n[0] >= 2 && h->dims.n[0] <= 16) {
+            const int tps = (int)((M1 + 15) / 16);
+            const long mtg = (long)tps * h->dims.n[0];
+            // padding must stay cheap: at most 15 % more row tiles than the plain plan
+            if (mtg * 100 <= (long)p.MT * 115) {
+                std::vector<unsigned> rc((size_t)mtg * 16);
+                for (long t = 0; t < mtg; ++t)
+                    for (int r = 0; r < 16; ++r) {
+                        const long m1 = (t % tps) * 16 + r;
+                        unsigned f[PCX_CODE_FIELDS] = {ones_h, ones_h, ones_h, ones_h};
+                        if (m1 < M1) {
+                            long rem = m1;
+                            for (int k = p.split - 1; k >= 1; --k) {
+                                int i = (int)(rem % h->dims.n[k]);
+                                rem /= h->dims.n[k];
+                                f[k - 1] = (unsigned)(h->dims.off[k] + i);
+                            }
+                        }
+                        rc[(size_t)16 * t + r] = f[0] | (f[1] << 8) | (f[2] << 16) | (f[3] << 24);
+                    }
+                std::vector<unsigned> o(rc.size());
+                for (long t = 0; t < mtg; ++t)
+                    for (int g = 0; g < 4; ++g)
+                        for (int j = 0; j < 4; ++j) o[(size_t)(4 * t + g) * 4 + j] = rc[(size_t)16 * t + g + 4 * j];
+                CREATE_TRY(hipMalloc((void **)&h->d_rowcode_g0, o.size() * sizeof(unsigned)));
+                CREATE_TRY(hipMemcpy(h->d_rowcode_g0, o.data(), o.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+                h->g0_ok = true;
+                h->g0_tps = tps;
+                h->g0_nf = std::max(2, p.split - 1);
+            }
+        }
     }
 
     // value tensor (derivative spec all-zero) enters the cache at create
@@ -798,7 +856,7 @@ static int launch_mfma_t(pcx_bary *h, const double *const *frag_tab, int m, cons
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)blocks, (unsigned)nsplit, (unsigned)m), dim3(256), lds, st,
                        h->dims, h->plan, h->d_nodes, h->d_wts, frag_tab, h->d_rowcode, h->d_kcode,
-                       h->d_rowcode_hi, h->d_kcode_hi, d_pts, d_out, N, ostride, ooff, cps, partial, perm);
+                       h->d_rowcode_hi, h->d_kcode_hi, d_pts, d_out, N, ostride, ooff, cps, partial, perm, BaryG0{}, nullptr);
     HIP_TRY(hipGetLastError());
     if (nsplit > 1) {
         long cnt = N * m;
@@ -930,6 +988,64 @@ static int launch_small(pcx_bary *h, const DerivedTensor &dt, const double *cons
     return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
 }
 
+
+// ---- dim-0 group launches (BaryG0) --------------------------------------------------------------
+// Slab-packs dt.plain on first use (caller holds h->mu; enqueued on h->stream and synchronised).
+static int bary_pack_g0(pcx_bary *h, DerivedTensor &dt) {
+    if (dt.frag_g0) return PCX_OK;
+    const BaryMfmaPlan &p = h->plan;
+    const int n0 = h->dims.n[0];
+    const size_t cnt = (size_t)n0 * h->g0_tps * p.KS * 64;
+    DevBuf frag, slot;
+    int rc = frag.alloc(cnt * sizeof(double));
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_pack_fragments_slabs, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, dt.plain,
+                       frag.as<double>(), n0, p.M / n0, p.K, h->g0_tps, p.KS);
+    HIP_TRY(hipGetLastError());
+    if ((rc = slot.alloc(sizeof(double *)))) return rc;
+    double *fp = frag.as<double>();
+    HIP_TRY(hipMemcpy(slot.p, &fp, sizeof(double *), hipMemcpyHostToDevice));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    dt.frag_g0 = frag.release<double>();
+    dt.slot_g0 = slot.release<double *>();
+    return PCX_OK;
+}
+
+template <int KS, int NF>
+static int launch_g0_t(pcx_bary *h, const DerivedTensor &base, const BaryG0 &gs, const double *d_pts, long N, double *d_out,
+                       long ostride, long ooff, hipStream_t st) {
+    auto kern = k_bary_mfma<KS, 2, false, NF, true>;
+    const size_t lds = mfma_lds_bytes(h->dims, 2);
+    if (lds > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const long blocks = (N + 127) / 128;
+    if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+    BaryMfmaPlan plan = h->plan;
+    plan.MT = gs.tps * gs.n0;
+    const int nchunks = (plan.MT + PCX_CHUNK_TILES - 1) / PCX_CHUNK_TILES;
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, 1), dim3(256), lds, st, h->dims, plan, h->d_nodes, h->d_wts,
+                       (const double *const *)base.slot_g0, h->d_rowcode_g0, h->d_kcode, nullptr, nullptr, d_pts, d_out, N,
+                       ostride, ooff, nchunks, nullptr, nullptr, gs, h->d_diff + h->doff[0]);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+template <int NF>
+static int launch_g0_nf(pcx_bary *h, const DerivedTensor &base, const BaryG0 &gs, const double *d_pts, long N, double *d_out,
+                        long ostride, long ooff, hipStream_t st) {
+    switch (h->plan.KS) {
+#define CASE_KS(v) case v: return launch_g0_t<v, NF>(h, base, gs, d_pts, N, d_out, ostride, ooff, st);
+        CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8)
+        CASE_KS(9) CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
+        CASE_KS(17) CASE_KS(18) CASE_KS(19) CASE_KS(20) CASE_KS(21) CASE_KS(22) CASE_KS(23) CASE_KS(24)
+        CASE_KS(25) CASE_KS(26) CASE_KS(27) CASE_KS(28) CASE_KS(29) CASE_KS(30) CASE_KS(31) CASE_KS(32)
+#undef CASE_KS
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "no dim-0 group instantiation for KS=%d", h->plan.KS);
+}
+
+static const long kG0MinPoints = 65536;      // below: per-spec launches (they split over row tiles and need no second pass)
+
 // the kernel a launch will take: 1 rows, 2 MFMA 16x16x4, 3 MFMA 4x4x4, 4 lane-per-point
 static int bary_effective_variant(const pcx_bary *h) {
     if (h->variant != 0) return h->variant;
@@ -966,6 +1082,78 @@ static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const doub
     }
     for (int s = 0; s < m; ++s) {
         int rc = launch_rows(h, *dts[s], d_pts, N, d_out, ostride, ooff + s, st, perm);
+        if (rc) return rc;
+    }
+    return PCX_OK;
+}
+
+// Multi-spec launch with dim-0 groups: specs (rows of `derivs`, m x d) that differ only in their order along
+// dimension 0 by at most g_g0_span -- price / delta; vega / vanna -- share one slab-packed GEMM over the tensor of the
+// lower order (the reference's own order in vectorized_eval_multi, barycentric.py:1098-1110: contract the later
+// dimensions, then apply D_0); every other spec keeps its own GEMM, launched in runs of consecutive columns.
+// Large batches on the MFMA kernel only; results of grouped specs differ from the per-spec path by rounding
+// (<= 2e-13 of the scale on 5-D Black-Scholes), as the reference's multi and batch paths do.  Caller holds h->mu.
+static int bary_launch_specs(pcx_bary *h, const int32_t *derivs, DerivedTensor *const *dts, int m,
+                             const double *const *frag_tab, const double *d_pts, long N, double *d_out, long ostride,
+                             long ooff, hipStream_t st, Scratch *split_scratch) {
+    const int d = h->dims.d;
+    // a sub-group = the specs one slab GEMM serves: equal orders along dimensions 1 .. d-1 and dim-0 orders in
+    // [base, base + g_g0_span]
+    struct Sub { int base; std::vector<int> members; };
+    std::vector<Sub> subs;
+    std::vector<char> grouped(m, 0);
+    const int g_g0_span = h->g0_span;
+    if (g_g0_span > 0 && derivs && m > 1 && h->g0_ok && N >= kG0MinPoints && bary_effective_variant(h) == 2) {
+        std::map<std::vector<int>, std::vector<int>> by_key;       // orders[1:] -> specs, in column order
+        for (int s = 0; s < m; ++s)
+            by_key[std::vector<int>(derivs + (size_t)s * d + 1, derivs + (size_t)(s + 1) * d)].push_back(s);
+        for (auto &kv : by_key) {
+            std::vector<int> &mem = kv.second;
+            if (mem.size() < 2) continue;
+            std::sort(mem.begin(), mem.end(), [&](int a, int b) {
+                const int oa = derivs[(size_t)a * d], ob = derivs[(size_t)b * d];
+                return oa != ob ? oa < ob : a < b;
+            });
+            for (size_t i = 0; i < mem.size();) {
+                const int base = derivs[(size_t)mem[i] * d];
+                size_t e = i;
+                while (e < mem.size() && derivs[(size_t)mem[e] * d] <= base + g_g0_span && e - i < PCX_G0_MAX) ++e;
+                if (e - i >= 2) {
+                    subs.push_back(Sub{base, std::vector<int>(mem.begin() + i, mem.begin() + e)});
+                    for (size_t q = i; q < e; ++q) grouped[mem[q]] = 1;
+                }
+                i = e;
+            }
+        }
+    }
+    // runs of consecutive ungrouped specs: ordinary launches
+    for (int s = 0; s < m;) {
+        if (grouped[s]) { ++s; continue; }
+        int e = s;
+        while (e < m && !grouped[e]) ++e;
+        int rc = bary_launch(h, dts + s, e - s, (e - s == 1) ? (const double *const *)dts[s]->slot : frag_tab + s, d_pts, N,
+                             d_out, ostride, ooff + s, st, split_scratch);
+        if (rc) return rc;
+        s = e;
+    }
+    for (const Sub &sub : subs) {
+        std::vector<int32_t> bspec(derivs + (size_t)sub.members[0] * d, derivs + (size_t)(sub.members[0] + 1) * d);
+        bspec[0] = sub.base;
+        DerivedTensor *base = nullptr;
+        int rc = bary_get_tensor(h, bspec.data(), &base);
+        if (rc) return rc;
+        if ((rc = bary_pack_g0(h, *base))) return rc;
+        BaryG0 gs{};
+        gs.nmem = (int)sub.members.size();
+        gs.tps = h->g0_tps;
+        gs.n0 = h->dims.n[0];
+        for (int i = 0; i < gs.nmem; ++i) {
+            gs.order[i] = derivs[(size_t)sub.members[i] * d] - sub.base;
+            gs.col[i] = sub.members[i];
+            gs.maxorder = std::max(gs.maxorder, gs.order[i]);
+        }
+        rc = (h->g0_nf == 2) ? launch_g0_nf<2>(h, *base, gs, d_pts, N, d_out, ostride, ooff, st)
+                             : launch_g0_nf<3>(h, *base, gs, d_pts, N, d_out, ostride, ooff, st);
         if (rc) return rc;
     }
     return PCX_OK;
@@ -1020,8 +1208,8 @@ extern "C" int pcx_bary_eval_multi_batch_dev(pcx_bary *h, const double *d_pts, i
             }
             frag_tab = h->d_tab;
         }
-        int rc = bary_launch(h, dts.data(), mc, frag_tab, d_pts, (long)N, d_out, m, s0, st,
-                             st == h->stream ? &h->s_partial : nullptr);
+        int rc = bary_launch_specs(h, derivs + (size_t)s0 * d, dts.data(), mc, frag_tab, d_pts, (long)N, d_out, m, s0, st,
+                                   st == h->stream ? &h->s_partial : nullptr);
         if (rc) return rc;
     }
     return PCX_OK;
@@ -1108,7 +1296,7 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         if (rc) return rc;
         double *dp = (double *)sp.ptr, *dout = (double *)so.ptr;
         HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
-        rc = bary_launch(h, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial);
+        rc = bary_launch_specs(h, derivs, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial);
         if (rc) return rc;
         if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
         if (chunk != kPipeChunkPoints) {          // single slot: drain before its buffers are reused
@@ -1189,6 +1377,14 @@ extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
     if (variant == 3 && !h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
     std::lock_guard<std::mutex> lk(h->mu);
     h->variant = variant;
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_set_group_span(pcx_bary *h, int span) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (span < 0 || span > 8) return fail(PCX_ERR_INVALID, "span %d outside [0, 8]", span);
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->g0_span = span;
     return PCX_OK;
 }
 

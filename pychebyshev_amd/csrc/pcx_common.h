@@ -38,6 +38,21 @@ struct BaryMfmaPlan {
     int rows;       // table rows (= sum_n + 2)
 };
 
+// A "dim-0 group" of a multi-spec launch: specs that differ only in their derivative order along dimension 0
+// share ONE contraction of dimensions 1 .. d-1 (reference vectorized_eval_multi, barycentric.py:1098-1110:
+// contract the later dimensions, THEN apply D_0, then contract dimension 0).  The GEMM rows are laid out in
+// slabs of one i0 each (padded to whole row tiles), the kernel keeps the n0 per-i0 partial sums P of a point
+// and finishes with g = D_0^o P and y = b_0 . g on the VALU.
+#define PCX_G0_MAX 9
+struct BaryG0 {
+    int nmem;                // members of the group (0: ordinary launch)
+    int maxorder;            // highest dim-0 order among them
+    int tps;                 // row tiles per dim-0 slab
+    int n0;                  // nodes of dimension 0 (= slabs)
+    int order[PCX_G0_MAX];   // dim-0 derivative order of member s
+    int col[PCX_G0_MAX];     // output column of member s
+};
+
 // ---- tensor-train kernel parameters ---------------------------------------------
 struct TTDims {
     int d;

@@ -81,16 +81,23 @@ class HostGroup:
                 f.write(b"\0" * (world * _SLOT))
             os.rename(tmp, self.path)                    # appears complete or not at all
         deadline = time.monotonic() + timeout
+        self._ino = None
         while True:
             try:
                 fd = os.open(self.path, os.O_RDWR)
                 try:
-                    if os.fstat(fd).st_size == size:
+                    st = os.fstat(fd)
+                    if st.st_size == size:
                         head = os.pread(fd, 24, 0)
                         magic, w, created = struct.unpack("<qqq", head)
                         fresh = abs(time.time_ns() - created) < 900e9
-                        if magic == _MAGIC and w == world and fresh:
+                        # A file left by a crashed run with the same key is recognised by this rank's own slot:
+                        # only its owner ever writes a slot, so in the file of THIS launch its generation is
+                        # still 0 (rank 0 unlinks and recreates the file; wait for the new one).
+                        (own_gen,) = struct.unpack("<q", os.pread(fd, 8, _HDR + rank * _SLOT))
+                        if magic == _MAGIC and w == world and fresh and own_gen == 0 and self._same_file(st):
                             self._mm = mmap.mmap(fd, size)
+                            self._ino = (st.st_dev, st.st_ino)
                             break
                 finally:
                     os.close(fd)
@@ -101,7 +108,23 @@ class HostGroup:
             time.sleep(0.002)
         self._gens = np.frombuffer(self._mm, dtype=np.int64, count=world * (_SLOT // 8),
                                    offset=_HDR)[:: _SLOT // 8]
+        self._attached = False           # until the first barrier passes, keep checking that the path still names this file
         self.barrier()
+        self._attached = True
+
+    def _same_file(self, st) -> bool:
+        """The path still names the file behind `st` (rank 0 replaces a stale file by unlink + rename)."""
+        try:
+            now = os.stat(self.path)
+        except FileNotFoundError:
+            return False
+        return (now.st_dev, now.st_ino) == (st.st_dev, st.st_ino)
+
+    def subgroup(self, name: str, timeout: Optional[float] = None) -> "HostGroup":
+        """A second, independent group of the same ranks (own file, own generation counters) -- for a helper
+        thread whose collectives must not interleave with the main thread's.  Collective: every rank calls it."""
+        return HostGroup(self.rank, self.world, os.path.join(self.directory, name),
+                         self.timeout if timeout is None else timeout)
 
     # -- construction from the launcher's environment ---------------------------------
     @classmethod
@@ -130,6 +153,15 @@ class HostGroup:
             spins += 1
             if spins > 200:
                 time.sleep(0.0002)
+                if not self._attached and spins % 1000 == 0:
+                    now = None
+                    try:
+                        now = os.stat(self.path)
+                    except FileNotFoundError:
+                        pass
+                    if now is None or (now.st_dev, now.st_ino) != self._ino:
+                        raise TimeoutError(f"rank {self.rank}: attached to a stale rendezvous file {self.path} "
+                                           "(replaced by rank 0 of this launch); start the ranks again")
                 if time.monotonic() > deadline:
                     late = [r for r in range(self.world) if int(self._gens[r]) < gen]
                     raise TimeoutError(f"rank {self.rank}: ranks {late} did not reach barrier {gen}")
@@ -157,12 +189,16 @@ class HostGroup:
     def broadcast_bytes(self, blob: Optional[bytes], src: int = 0) -> bytes:
         return self.allgather_bytes(blob if self.rank == src else b"")[src]
 
-    def max(self, value: float) -> float:
-        vals = self.allgather_bytes(struct.pack("<d", float(value)))
-        return max(struct.unpack("<d", v)[0] for v in vals)
-
     def gather_floats(self, value: float):
-        return [struct.unpack("<d", v)[0] for v in self.allgather_bytes(struct.pack("<d", float(value)))]
+        vals = self.allgather_bytes(struct.pack("<d", float(value)))
+        bad = [r for r, v in enumerate(vals) if len(v) != 8]
+        if bad:       # another rank was in a different collective: say so instead of failing in struct.unpack
+            raise RuntimeError(f"rank {self.rank}: ranks {bad} answered a float gather with {[len(vals[r]) for r in bad]} "
+                               "bytes -- the ranks are not running the same sequence of collectives")
+        return [struct.unpack("<d", v)[0] for v in vals]
+
+    def max(self, value: float) -> float:
+        return max(self.gather_floats(value))
 
     def close(self):
         if getattr(self, "_mm", None) is None:
@@ -253,10 +289,23 @@ class RcclComm:
         self._libmod = _lib
         self.lib = _lib.load()
         self.group, self.device = group, device
-        uid = ctypes.create_string_buffer(128)
+        # The broadcast is unconditional: if rank 0 cannot draw the id (librccl missing, ...) it still takes part,
+        # sending a status byte + message, and EVERY rank raises after the collective -- a rank that raised before
+        # it would leave the others pairing this broadcast with whatever collective rank 0 runs next.
+        msg = b""
         if group.rank == 0:
-            _lib.check(self.lib.pcx_comm_unique_id(uid), self.lib)
-        blob = group.broadcast_bytes(uid.raw if group.rank == 0 else None, 0)
+            uid = ctypes.create_string_buffer(128)
+            rc = self.lib.pcx_comm_unique_id(uid)
+            if rc == 0:
+                msg = b"\x01" + uid.raw
+            else:
+                err = self.lib.pcx_last_error() or b"pcx_comm_unique_id failed"
+                msg = b"\x00" + bytes(err)[:300]
+        blob = group.broadcast_bytes(msg if group.rank == 0 else None, 0)
+        if len(blob) != 129 or blob[:1] != b"\x01":
+            raise RuntimeError("RCCL unique id unavailable on rank 0: "
+                               + (blob[1:].decode("utf-8", "replace") if len(blob) > 1 else "empty bootstrap message"))
+        blob = blob[1:]
         self.handle = ctypes.c_void_p()
         _lib.check(self.lib.pcx_comm_create(device, group.rank, group.world, blob, ctypes.byref(self.handle)),
                    self.lib)

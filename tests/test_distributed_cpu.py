@@ -135,3 +135,82 @@ def test_sharded_eval_under_torchrun_gloo(tmp_path):
                          env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "rank-0-ok" in res.stdout and "rank-1-ok" in res.stdout
+
+
+BOOT_WORKER = textwrap.dedent("""
+    import ctypes, os, sys
+    sys.path.insert(0, {root!r})
+    from pychebyshev_amd import _lib, distributed
+    from pychebyshev_amd.distributed import HostGroup, RcclComm
+    group = HostGroup.from_env(timeout=60)
+    boot = group.subgroup("rccl_boot")                 # what bench.py does: the bootstrap has its own counters
+
+    class NoRccl:                                      # a library whose RCCL cannot be loaded (rank 0 draws the id)
+        def pcx_comm_unique_id(self, uid):
+            return -7
+        def pcx_last_error(self):
+            return b"librccl.so.1: cannot open shared object file"
+    _lib.load = lambda: NoRccl()
+    try:
+        RcclComm(boot, 0)
+        raise SystemExit("RcclComm did not raise")
+    except RuntimeError as exc:
+        assert "cannot open shared object" in str(exc), exc
+    # the main group is still in step on every rank: the collective bench.py runs next
+    flags = group.gather_floats(1.0)
+    assert flags == [1.0, 1.0], flags
+    assert group.max(float(group.rank)) == 1.0
+    boot.close()
+    group.close()
+    sys.stdout.write("rank-%d-ok\\n" % group.rank)
+""")
+
+
+def test_rccl_bootstrap_failure_keeps_the_ranks_in_step(tmp_path):
+    """rank 0 failing to draw the RCCL unique id must not leave the other ranks inside a broadcast that
+    rank 0 never joins.  The broadcast is unconditional (status byte + id or message); every rank raises after it,
+    and the next collective of the main group pairs up on all ranks."""
+    script = tmp_path / "boot_worker.py"
+    script.write_text(BOOT_WORKER.format(root=ROOT))
+    rdzv = tmp_path / "rdzv"
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", PCX_RDZV_DIR=str(rdzv))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=120) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, f"rank {r}: {so[-1000:]}{se[-3000:]}"
+        assert f"rank-{r}-ok" in so
+
+
+def test_stale_rendezvous_file_is_not_attached(tmp_path):
+    """a group.bin left by a crashed run with the same key (right magic and world size, recent, generation
+    counters already high) must not be attached by a rank that starts before rank 0 has replaced it."""
+    import struct
+    import threading
+    import time
+    from pychebyshev_amd import distributed as D
+    d = tmp_path / "rdzv"
+    d.mkdir()
+    stale = struct.pack("<qqq", D._MAGIC, 2, time.time_ns()).ljust(D._HDR, b"\0")
+    for r in range(2):
+        stale += (struct.pack("<qq", 57, 0)).ljust(D._SLOT, b"\0")       # both ranks were at barrier 57
+    (d / "group.bin").write_bytes(stale)
+    got = {}
+
+    def rank1():
+        g = D.HostGroup(1, 2, str(d), timeout=30)
+        got["gen1"] = int(g._gens[1])
+        g.barrier()
+        g.close()
+
+    th = threading.Thread(target=rank1)
+    th.start()
+    time.sleep(0.3)                     # rank 1 is polling: it must be ignoring the stale file
+    assert th.is_alive()
+    g0 = D.HostGroup(0, 2, str(d), timeout=30)
+    g0.barrier()
+    g0.close()
+    th.join(30)
+    assert not th.is_alive() and got["gen1"] == 1

@@ -289,6 +289,58 @@ def test_config2_one_million_points_properties(bs5d, oracle_mod):
     assert np.max(np.abs(ones.vectorized_eval_batch(pts[:200_000], [1, 0, 0, 0, 0]))) < 1e-11
 
 
+def test_dim0_groups_share_one_contraction_and_match_reference(bs5d):
+    """Large multi-spec batches (N >= 65,536 on the MFMA kernel): specs differing only in their dim-0 order --
+    price / delta / gamma; vega / vanna -- share one slab-packed GEMM and finish with D_0 on the per-i0 partial
+    sums (the reference's own order in vectorized_eval_multi, barycentric.py:1098-1110).  The golden batch
+    (4,432 points incl. OTM corner, domain edges, exact-node and near-node rows) tiled 15 times: all seven g2
+    specs <= 1e-12 normwise against the reference's batch results, exact-node rows bit for bit for the value
+    spec, every tile identical, and the per-spec path (what small batches take) within 5e-13."""
+    c, g = bs5d
+    specs = g["specs"].tolist()
+    reps = 15
+    n0 = len(g["points"])
+    pts = np.tile(g["points"], (reps, 1))
+    assert len(pts) >= 65536
+    got = c.vectorized_eval_multi_batch(pts, specs)
+    assert got.shape == (len(pts), len(specs))
+    for col, s in enumerate(specs):
+        ref = g["out"][col]
+        for r in (0, 7, reps - 1):
+            assert_parity(got[r * n0:(r + 1) * n0, col], ref, 1e-12, f"grouped {s} tile {r}", spec_point_tol(s))
+        assert np.array_equal(got[:n0, col], got[(reps - 1) * n0:, col]), s          # independent of the position in the batch
+        single = c.vectorized_eval_batch(pts[:n0], s)                                # per-spec path (small batch)
+        scale = np.max(np.abs(ref))
+        assert np.max(np.abs(got[:n0, col] - single)) <= 5e-13 * scale, s
+    assert np.array_equal(got[4352:4384, 0], g["out"][0][4352:4384])                  # all coordinates on nodes
+    # device-resident entry point takes the same path
+    from pychebyshev_amd.device import DeviceArray
+    dev = c.vectorized_eval_multi_batch(DeviceArray.from_host(pts), specs)
+    assert np.array_equal(dev.to_host(), got)
+    # a group whose members come in any order / with repeats, next to ungrouped columns
+    mixed = [[0, 0, 1, 0, 0], [2, 0, 0, 0, 0], [0, 0, 0, 0, 0], [0, 0, 0, 0, 1], [1, 0, 0, 0, 0], [0, 0, 0, 0, 0]]
+    gm = c.vectorized_eval_multi_batch(pts, mixed)
+    for col, s in enumerate(mixed):
+        assert np.array_equal(gm[:, col], got[:, specs.index(s)]), s
+
+
+def test_config4_one_million_points_all_six_greeks(bs5d, oracle_mod):
+    """BASELINE config 4 at full size (N = 10^6, seed 99, the six specs of compare_methods_time_accuracy.py:36-43
+    in one call): a 20k subset of every spec against the oracle, permutation equivariance bit for bit."""
+    c, g = bs5d
+    N = 1_000_000
+    pts = F.bs5_query_points(N, seed=99)
+    specs = [[0, 0, 0, 0, 0], [1, 0, 0, 0, 0], [2, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 0, 1, 0, 0], [0, 0, 0, 0, 1]]
+    got = c.vectorized_eval_multi_batch(pts, specs)
+    assert got.shape == (N, 6) and np.isfinite(got).all()
+    sub = np.random.default_rng(0).choice(N, 20_000, replace=False)
+    om = _oracle_model(oracle_mod, c)
+    for col, s in enumerate(specs):
+        assert_parity(got[sub, col], oracle_mod.bary_eval_batch(om, pts[sub], s), 1e-12, f"1M greeks {s}", float("inf"))
+    perm = np.random.default_rng(1).permutation(N)
+    assert np.array_equal(c.vectorized_eval_multi_batch(pts[perm], specs), got[perm])
+
+
 def test_device_resident_entry_point_matches_host_entry_point(bs5d):
     c, g = bs5d
     m = c._model()
