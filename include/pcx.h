@@ -120,6 +120,14 @@ int pcx_bary_eval_batch_dev(pcx_bary *h, const double *d_pts, int64_t N, const i
  * specs (m x d orders) at each of N points; out is (N, m) row-major.                  */
 int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs,
                               int m, double *out);
+/* The same over SEVERAL handles of one process (the same model created on several devices -- the
+ * "devices[] list" of a drop-in create): handle g evaluates the contiguous row
+ * block [g ceil(N/G), ...) on its own device from its own host thread, every download lands in its slice of
+ * `out`; no collective.  pin != 0: the caller's arrays are page-locked for the call (asynchronous copies at
+ * PCIe rate).  Replaces the reference's single-process vectorized_eval_batch (barycentric.py:992) when the
+ * process sees more than one GPU.                                                          */
+int pcx_bary_group_eval_multi_batch(pcx_bary *const *handles, int n_handles, const double *pts, int64_t N,
+                                    const int32_t *derivs, int m, double *out, int pin);
 /* Device-resident form: d_pts (N x d) and d_out (N x m) in HBM; enqueues on `stream`
  * (NULL = the handle's own) and returns without synchronizing.                         */
 int pcx_bary_eval_multi_batch_dev(pcx_bary *h, const double *d_pts, int64_t N,
@@ -213,6 +221,9 @@ int pcx_tt_destroy(pcx_tt *h);
 /* eval_batch (tensor_train.py:2217-2265): per storage dim scale to [-1,1], Chebyshev
  * polynomials T_0..T_{n-1}, contract with the core, chain-multiply.                   */
 int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double *out);
+/* eval_batch fanned out over several handles (one per device), as pcx_bary_group_eval_multi_batch
+ * (reference entry point: tensor_train.py:2217).                                            */
+int pcx_tt_group_eval_batch(pcx_tt *const *handles, int n_handles, const double *pts, int64_t N, double *out, int pin);
 int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, double *d_out, void *stream);
 int pcx_tt_stream(pcx_tt *h, void **stream);
 /* Kernel selection: 0 = auto, 1 = direct form on v_mfma_f64_16x16x4 (one GEMM over (node, left

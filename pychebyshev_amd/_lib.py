@@ -77,6 +77,7 @@ SIGNATURES = {
     "pcx_bary_eval_batch_dev": (_I, [_V, _V, _L, c_i32p, _V, _V]),
     "pcx_bary_eval_multi_batch": (_I, [_V, c_f64p, _L, c_i32p, _I, c_f64p]),
     "pcx_bary_eval_multi_batch_dev": (_I, [_V, _V, _L, c_i32p, _I, _V, _V]),
+    "pcx_bary_group_eval_multi_batch": (_I, [c_vpp, _I, c_f64p, _L, c_i32p, _I, c_f64p, _I]),
     "pcx_bary_derivative_tensor": (_I, [_V, c_i32p, c_f64p]),
     "pcx_tensor_contract_axis": (_I, [_I, _I, c_i32p, c_f64p, _I, c_f64p, c_f64p]),
     "pcx_bary_set_kernel": (_I, [_V, _I]),
@@ -99,6 +100,7 @@ SIGNATURES = {
     "pcx_tt_destroy": (_I, [_V]),
     "pcx_tt_eval_batch": (_I, [_V, c_f64p, _L, c_f64p]),
     "pcx_tt_eval_batch_dev": (_I, [_V, _V, _L, _V, _V]),
+    "pcx_tt_group_eval_batch": (_I, [c_vpp, _I, c_f64p, _L, c_f64p, _I]),
     "pcx_tt_stream": (_I, [_V, c_vpp]),
     "pcx_tt_set_kernel": (_I, [_V, _I]),
     "pcx_tt_cross_step": (_I, [_I, c_f64p, _I, _I, _I, _D, c_f64p, c_i64p, c_i32p]),
@@ -182,6 +184,26 @@ def default_device() -> int:
         if v is not None and v.strip() != "":
             return int(v)
     return 0
+
+
+def fanout_devices():
+    """Devices a single process spreads host-pointer batches over, from ``PCX_DEVICES`` ("all" or a comma list
+    such as "0,1,2,3"); ``None`` when unset: one device per process (``default_device``)."""
+    v = os.environ.get("PCX_DEVICES", "").strip()
+    if not v:
+        return None
+    if v.lower() == "all":
+        return list(range(max(1, device_count())))
+    return [int(t) for t in v.split(",") if t.strip() != ""]
+
+
+# batches below this many rows per device stay on one device (launch + thread start-up cost more than they save)
+FANOUT_MIN_ROWS_PER_DEVICE = 65536
+
+
+def handle_array(handles):
+    arr = (ctypes.c_void_p * len(handles))(*[h.value if isinstance(h, ctypes.c_void_p) else h for h in handles])
+    return ctypes.cast(arr, c_vpp), arr
 
 
 def f64(a) -> np.ndarray:

@@ -408,19 +408,61 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
             print(f"  Built in {self.build_time:.3f}s ({total_weights} weights, {total_weights * 8} bytes)")
 
     # ---------------------------------------------------------------- device plumbing
-    def to_device(self, device: int | None = None) -> "ChebyshevApproximation":
+    def to_device(self, device: int | None = None, *, devices=None) -> "ChebyshevApproximation":
         """Upload (or re-upload) the model to GPU ``device`` (default: ``PCX_DEVICE`` /
-        ``LOCAL_RANK`` / 0).  Called lazily by the first evaluation."""
+        ``LOCAL_RANK`` / 0).  Called lazily by the first evaluation.
+
+        ``devices`` (a list of device indices, or ``"all"``; default: the ``PCX_DEVICES`` environment variable):
+        replicate the model on several GPUs of this process -- large host-pointer batches are then split into
+        contiguous row blocks, one per device, evaluated concurrently (``pcx_bary_group_eval_multi_batch``; the
+        model is <= a few MB, the batch is what is sharded: SURVEY.md 8e).  Single-point calls, device-resident
+        batches and small batches keep using the first device."""
         if self.tensor_values is None:
             raise RuntimeError("Call build() first")
+        if devices is None and device is None:
+            devices = _lib.fanout_devices()
+        if isinstance(devices, str):
+            if devices.lower() != "all":
+                raise ValueError("devices must be a list of device indices or 'all'")
+            devices = list(range(max(1, _lib.device_count())))
+        if devices is not None:
+            devices = [int(v) for v in devices]
+            if not devices:
+                raise ValueError("devices is empty")
+            device = devices[0]
         dev = _lib.default_device() if device is None else int(device)
         self._device_index = dev
         self._device_model = _DeviceModel(self, dev)
+        self._fanout = [self._device_model] + [_DeviceModel(self, g) for g in (devices or [])[1:]]
+        self._fanout_devices = list(devices) if devices else None
         return self
 
     def invalidate_device_cache(self) -> None:
         """Drop the device copy (call after mutating ``tensor_values`` in place)."""
         self._device_model = None
+        self._fanout = []
+
+    def _fanout_models(self, n_rows: int):
+        """The handles a host-pointer batch of ``n_rows`` is spread over (one entry: no fan-out)."""
+        m = self._model()
+        group = [g for g in getattr(self, "_fanout", []) if g.tensor_ref is self.tensor_values]
+        if len(group) < 2 or group[0] is not m:
+            return [m]
+        use = max(1, min(len(group), n_rows // _lib.FANOUT_MIN_ROWS_PER_DEVICE))
+        return group[:use]
+
+    def _eval_host(self, pts: np.ndarray, specs: np.ndarray, out: np.ndarray) -> None:
+        """``out`` (N, m) or (N,) <- the m specs at the host-resident points, on one device or fanned out."""
+        models = self._fanout_models(pts.shape[0])
+        m0 = models[0]
+        k = specs.reshape(-1, self.num_dimensions).shape[0]
+        if len(models) == 1:
+            _lib.check(m0.lib.pcx_bary_eval_multi_batch(m0.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_i32(specs), k,
+                                                        _lib.p_f64(out)), m0.lib)
+            return
+        harr, keep = _lib.handle_array([g.handle for g in models])
+        _lib.check(m0.lib.pcx_bary_group_eval_multi_batch(harr, len(models), _lib.p_f64(pts), pts.shape[0],
+                                                          _lib.p_i32(specs), k, _lib.p_f64(out), 1), m0.lib)
 
     def _model(self) -> _DeviceModel:
         """The device copy for ``_device_index`` (default device when unset); rebuilt when
@@ -428,7 +470,13 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         m = self._device_model
         want = _lib.default_device() if self._device_index is None else int(self._device_index)
         if m is None or m.tensor_ref is not self.tensor_values or m.device != want:
-            self.to_device(want)
+            fan = getattr(self, "_fanout_devices", None)
+            if fan:
+                self.to_device(devices=fan)
+            elif self._device_index is None:
+                self.to_device()                      # PCX_DEVICES, if set, replicates the model
+            else:
+                self.to_device(want)
             m = self._device_model
         return m
 
@@ -464,9 +512,7 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
             raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
         out = np.empty(pts.shape[0])
-        spec = self._check_orders(orders)
-        _lib.check(m.lib.pcx_bary_eval_batch(m.handle, _lib.p_f64(pts), pts.shape[0],
-                                             _lib.p_i32(spec), _lib.p_f64(out)), m.lib)
+        self._eval_host(pts, self._check_orders(orders), out)
         return out
 
     # ---------------------------------------------------------------- evaluation API
@@ -522,9 +568,7 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
             raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
         out = np.empty((pts.shape[0], specs.shape[0]))
-        _lib.check(m.lib.pcx_bary_eval_multi_batch(m.handle, _lib.p_f64(pts), pts.shape[0],
-                                                   _lib.p_i32(specs), specs.shape[0],
-                                                   _lib.p_f64(out)), m.lib)
+        self._eval_host(pts, specs, out)
         return out
 
     # aliases for the words BASELINE.json uses; the reference names above stay primary
@@ -739,6 +783,8 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         state["function"] = None
         state.pop("_device_model", None)
         state.pop("_device_index", None)
+        state.pop("_fanout", None)
+        state.pop("_fanout_devices", None)
         state["_pychebyshev_version"] = __version__
         return state
 

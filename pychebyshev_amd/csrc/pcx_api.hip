@@ -12,6 +12,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "bary_kernels.h"
@@ -1329,6 +1330,71 @@ extern "C" int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t
     return bary_eval_host(h, pts, N, derivs, m, out);
 }
 
+// ---------------------------------------------------------------------------------
+// Single-process fan-out over several devices (contiguous row blocks, model replicated, "G parallel
+// D2H copies straight into the host result", no collective).  handles[g] is the same model on device g (the same
+// device may appear twice: two handles then pipeline on it); block g = rows [g ceil(N/G), min(N, (g+1) ceil(N/G)))
+// is evaluated by the ordinary host-pointer path of handle g on its own host thread, its download landing in the
+// caller's `out` slice.  pin != 0 page-locks the caller's arrays for the duration of the call (hipHostRegister,
+// portable): the copies then run asynchronously at PCIe rate instead of through the driver's pageable staging.
+// A point's result does not depend on the block it lands in (for grouped multi-spec launches: as long as every
+// block stays above the 65,536-point threshold of that path).
+// ---------------------------------------------------------------------------------
+struct HostPin {
+    void *a = nullptr, *b = nullptr;
+    void pin(const void *p, size_t bytes, void **slot) {
+        if (p && bytes && hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess) *slot = const_cast<void *>(p);
+        else (void)hipGetLastError();          // already registered / not page-lockable: the pageable path still works
+    }
+    ~HostPin() {
+        if (a) (void)hipHostUnregister(a);
+        if (b) (void)hipHostUnregister(b);
+    }
+};
+
+template <typename Fn>
+static int fan_out(int n_handles, int64_t N, Fn &&block_call) {
+    const int64_t per = (N + n_handles - 1) / n_handles;
+    std::vector<int> rcs(n_handles, PCX_OK);
+    std::vector<std::string> errs(n_handles);
+    std::vector<std::thread> th;
+    for (int g = 0; g < n_handles; ++g) {
+        const int64_t lo = std::min<int64_t>(N, (int64_t)g * per), hi = std::min<int64_t>(N, lo + per);
+        if (hi <= lo) continue;
+        th.emplace_back([&, g, lo, hi] {
+            rcs[g] = block_call(g, lo, hi - lo);
+            if (rcs[g]) errs[g] = g_err;            // g_err is thread-local: carry the message to the caller's thread
+        });
+    }
+    for (auto &t : th) t.join();
+    for (int g = 0; g < n_handles; ++g)
+        if (rcs[g]) return fail(rcs[g], "device block %d: %s", g, errs[g].c_str());
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_group_eval_multi_batch(pcx_bary *const *handles, int n_handles, const double *pts, int64_t N,
+                                               const int32_t *derivs, int m, double *out, int pin) {
+    if (!handles || n_handles < 1) return fail(PCX_ERR_INVALID, "no handles");
+    for (int g = 0; g < n_handles; ++g) {
+        if (!handles[g]) return fail(PCX_ERR_INVALID, "handle %d is NULL", g);
+        if (handles[g]->dims.d != handles[0]->dims.d || handles[g]->total != handles[0]->total)
+            return fail(PCX_ERR_INVALID, "handle %d holds a different model", g);
+    }
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (n_handles == 1 || N == 0) return bary_eval_host(handles[0], pts, N, derivs, m, out);
+    const int d = handles[0]->dims.d;
+    HostPin hp;
+    if (pin) {
+        HIP_TRY(hipSetDevice(handles[0]->device));
+        hp.pin(pts, (size_t)N * d * sizeof(double), &hp.a);
+        hp.pin(out, (size_t)N * m * sizeof(double), &hp.b);
+    }
+    return fan_out(n_handles, N, [&](int g, int64_t lo, int64_t cnt) {
+        return bary_eval_host(handles[g], pts + (size_t)lo * d, cnt, derivs, m, out + (size_t)lo * m);
+    });
+}
+
 extern "C" int pcx_bary_derivative_tensor(pcx_bary *h, const int32_t *deriv, double *tensor_out) {
     if (!h || !tensor_out) return fail(PCX_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(h->device));
@@ -2445,6 +2511,28 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
     return PCX_OK;
+}
+
+extern "C" int pcx_tt_group_eval_batch(pcx_tt *const *handles, int n_handles, const double *pts, int64_t N, double *out,
+                                       int pin) {
+    if (!handles || n_handles < 1) return fail(PCX_ERR_INVALID, "no handles");
+    for (int g = 0; g < n_handles; ++g) {
+        if (!handles[g]) return fail(PCX_ERR_INVALID, "handle %d is NULL", g);
+        if (handles[g]->dims.d != handles[0]->dims.d) return fail(PCX_ERR_INVALID, "handle %d holds a different model", g);
+    }
+    if (N < 0) return fail(PCX_ERR_INVALID, "N < 0");
+    if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (n_handles == 1 || N == 0) return pcx_tt_eval_batch(handles[0], pts, N, out);
+    const int d = handles[0]->dims.d;
+    HostPin hp;
+    if (pin) {
+        HIP_TRY(hipSetDevice(handles[0]->device));
+        hp.pin(pts, (size_t)N * d * sizeof(double), &hp.a);
+        hp.pin(out, (size_t)N * sizeof(double), &hp.b);
+    }
+    return fan_out(n_handles, N, [&](int g, int64_t lo, int64_t cnt) {
+        return pcx_tt_eval_batch(handles[g], pts + (size_t)lo * d, cnt, out + lo);
+    });
 }
 
 extern "C" int pcx_tt_set_kernel(pcx_tt *h, int variant) {

@@ -477,21 +477,42 @@ class ChebyshevTT(ErgonomicsMixin):
             raise RuntimeError("Call build() before using this method.")
 
     # ---------------------------------------------------------------- device plumbing
-    def to_device(self, device: int | None = None) -> "ChebyshevTT":
+    def to_device(self, device: int | None = None, *, devices=None) -> "ChebyshevTT":
+        """Upload the cores to GPU ``device``; ``devices`` (list or ``"all"``; default ``PCX_DEVICES``) replicates
+        them on several GPUs of this process, and large host-pointer batches are split into one contiguous row
+        block per device (``pcx_tt_group_eval_batch``), as ``ChebyshevApproximation.to_device`` describes."""
         self._check_built()
+        if devices is None and device is None:
+            devices = _lib.fanout_devices()
+        if isinstance(devices, str):
+            if devices.lower() != "all":
+                raise ValueError("devices must be a list of device indices or 'all'")
+            devices = list(range(max(1, _lib.device_count())))
+        if devices is not None:
+            devices = [int(v) for v in devices]
+            if not devices:
+                raise ValueError("devices is empty")
+            device = devices[0]
         dev = _lib.default_device() if device is None else int(device)
         self._device_index = dev
         self._device_tt = _DeviceTT(self, dev)
+        self._fanout = [self._device_tt] + [_DeviceTT(self, g) for g in (devices or [])[1:]]
+        self._fanout_devices = list(devices) if devices else None
         return self
 
     def invalidate_device_cache(self) -> None:
         self._device_tt = None
+        self._fanout = []
 
     def _dev(self) -> _DeviceTT:
         t = self._device_tt
         key = (id(self._coeff_cores), tuple(id(c) for c in self._coeff_cores), tuple(self._dim_order))
         if t is None or t.key != key:
-            self.to_device(self._device_index)
+            fan = getattr(self, "_fanout_devices", None)
+            if fan:
+                self.to_device(devices=fan)
+            else:
+                self.to_device(self._device_index)    # None: PCX_DEVICES, if set, replicates the cores
             t = self._device_tt
         return t
 
@@ -513,7 +534,13 @@ class ChebyshevTT(ErgonomicsMixin):
         if pts.ndim != 2 or pts.shape[1] != self.num_dimensions:
             raise ValueError(f"points must have shape (N, {self.num_dimensions}), got {pts.shape}")
         out = np.empty(pts.shape[0])
-        _lib.check(t.lib.pcx_tt_eval_batch(t.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_f64(out)), t.lib)
+        group = [g for g in getattr(self, "_fanout", []) if g.key == t.key]
+        use = max(1, min(len(group), pts.shape[0] // _lib.FANOUT_MIN_ROWS_PER_DEVICE)) if group and group[0] is t else 1
+        if use > 1:
+            harr, keep = _lib.handle_array([g.handle for g in group[:use]])
+            _lib.check(t.lib.pcx_tt_group_eval_batch(harr, use, _lib.p_f64(pts), pts.shape[0], _lib.p_f64(out), 1), t.lib)
+        else:
+            _lib.check(t.lib.pcx_tt_eval_batch(t.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_f64(out)), t.lib)
         return out
 
     def _storage_to_user(self, pts_storage: np.ndarray) -> np.ndarray:
@@ -763,6 +790,8 @@ class ChebyshevTT(ErgonomicsMixin):
         state["function"] = None
         state.pop("_device_tt", None)
         state.pop("_device_index", None)
+        state.pop("_fanout", None)
+        state.pop("_fanout_devices", None)
         state["_pychebyshev_version"] = __version__
         return state
 

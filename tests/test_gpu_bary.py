@@ -797,3 +797,58 @@ def test_lane_per_point_kernel_large_batches(oracle_mod, shape):
         multi = c.vectorized_eval_multi_batch(pts, specs)
         assert np.array_equal(multi[:, 0], c.vectorized_eval_batch(pts, specs[0]))
         assert np.array_equal(multi[:, 1], big)
+
+
+@pytest.mark.parametrize("shape", [(12, 12), (9, 7, 6), (16,), (5, 4, 3, 6)])
+def test_near_node_points_through_the_lane_per_point_kernel(oracle_mod, shape):
+    """Coordinates within 1e-14 of a node but not on it (node +- 3e-15, as g2's `near` rows,
+    tests/golden/generate_golden.py:103-105): the reference returns the node's slice there
+    (barycentric.py:1039-1043); k_bary_small evaluates the interpolant at x itself (its weights come from
+    prefix / suffix products) -- the two differ by O(1e-14 |f'|), inside the 1e-12 bar.  Against the oracle,
+    which applies the reference's rule literally."""
+    rng = np.random.default_rng(100 + sum(shape))
+    d = len(shape)
+    T = rng.standard_normal(shape)
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-3, 3, d), rng.uniform(0.5, 3, d))]
+    c = ChebyshevApproximation.from_values(T, d, dom, list(shape))
+    om = _oracle_model(oracle_mod, c)
+    _set_kernel(c, 4)
+    n = 256
+    pts = np.column_stack([rng.uniform(lo, hi, n) for lo, hi in dom])
+    for r in range(n):                                  # every row: one or two coordinates next to a node
+        for k in rng.choice(d, size=min(d, 1 + r % 2), replace=False):
+            node = c.nodes[k][rng.integers(0, shape[k])]
+            pts[r, k] = node + (3e-15 if r % 3 else -4e-15) * max(1.0, abs(node))
+    specs = [[0] * d] + ([[1] + [0] * (d - 1)] if shape[0] > 2 else [])
+    for s in specs:
+        ref = oracle_mod.bary_eval_batch(om, pts, s)
+        got = c.vectorized_eval_batch(pts, s)
+        assert np.isfinite(got).all()
+        assert_parity(got, ref, 1e-12, f"near-node {shape} {s}", float("inf"), floor=np.max(np.abs(T)))
+
+
+def test_single_process_fan_out_over_device_handles(bs5d):
+    """one process, several device handles -- contiguous row blocks, one host thread per handle, every
+    download into its slice of the caller's array (pcx_bary_group_eval_multi_batch).  One GPU here: device 0 listed
+    twice and three times; results equal the single-handle call bit for bit (ragged N, value and multi-spec)."""
+    c, g = bs5d
+    N = 400_003
+    pts = F.bs5_query_points(N, seed=17)
+    specs = [[0, 0, 0, 0, 0], [1, 0, 0, 0, 0], [0, 0, 0, 1, 0]]
+    one = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES).to_device(0)
+    y1 = one.vectorized_eval_batch(pts, [0] * 5)
+    m1 = one.vectorized_eval_multi_batch(pts, specs)
+    for devs in ([0, 0], [0, 0, 0]):
+        fan = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES).to_device(devices=devs)
+        assert len(fan._fanout_models(N)) == len(devs) and len(fan._fanout_models(1000)) == 1
+        assert np.array_equal(fan.vectorized_eval_batch(pts, [0] * 5), y1)
+        assert np.array_equal(fan.vectorized_eval_multi_batch(pts, specs), m1)
+        assert np.array_equal(fan.vectorized_eval_batch(pts[:5000], [2, 0, 0, 0, 0]), one.vectorized_eval_batch(pts[:5000], [2, 0, 0, 0, 0]))
+        assert fan.vectorized_eval(list(pts[3]), [0] * 5) == y1[3]
+    # the C ABI refuses a group of different models and reports a failing block with its index
+    m = one._model()
+    other = ChebyshevApproximation.from_values(np.ones((3, 3)), 2, [[0, 1], [0, 1]], [3, 3]).to_device(0)._model()
+    harr, keep = _lib.handle_array([m.handle, other.handle])
+    out = np.empty(N)
+    assert m.lib.pcx_bary_group_eval_multi_batch(harr, 2, _lib.p_f64(pts), N, _lib.p_i32(_lib.i32([0] * 5)), 1,
+                                                 _lib.p_f64(out), 0) == _lib.PCX_ERR_INVALID

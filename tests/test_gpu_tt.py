@@ -222,6 +222,44 @@ def test_config3_ten_million_points_properties(oracle_mod):
     assert np.array_equal(tt.eval_batch(pts[tail][perm]), y[tail][perm])
 
 
+def test_config5_per_gpu_batch_properties(oracle_mod):
+    """BASELINE config 5 at its per-GPU size: 10^8 points over 8 GPUs = 12.5 M x 10 (1 GB) per rank, the golden rank-16
+    10-D cores (g5), shard 0's generator (default_rng(99), column-wise uniform).  A 100k subset against the oracle,
+    permutation equivariance on a tail block, and the sharded recipe itself: rank 3's rows of an 8-way split of a
+    smaller batch equal the same rows evaluated in one piece."""
+    g = golden("g5_tt_rank16")
+    cores = _cores(g, "", 10)
+    dom = [[-1.0, 1.0]] * 10
+    tt = ChebyshevTT.from_coeff_cores(cores, dom)
+    N = 12_500_000
+    rng = np.random.default_rng(99)
+    pts = np.column_stack([rng.uniform(-1.0, 1.0, N) for _ in range(10)])
+    y = tt.eval_batch(pts)
+    assert y.shape == (N,) and np.isfinite(y).all()
+    sub = np.random.default_rng(0).choice(N, 100_000, replace=False)
+    assert_parity(y[sub], oracle_mod.tt_eval_batch(cores, dom, pts[sub]), 1e-12, "config 5 per-GPU subset")
+    tail = slice(N - 500_003, N)
+    perm = np.random.default_rng(1).permutation(500_003)
+    assert np.array_equal(tt.eval_batch(pts[tail][perm]), y[tail][perm])
+    from pychebyshev_amd.distributed import shard_bounds
+    lo, hi = shard_bounds(1_000_000, 3, 8)
+    assert np.array_equal(tt.eval_batch(pts[lo:hi]), y[lo:hi])
+    del pts, y
+
+
+def test_tt_single_process_fan_out_over_device_handles():
+    """pcx_tt_group_eval_batch: device 0 listed twice equals the single-handle call bit for bit (ragged N)."""
+    g = golden("g4_tt_bs5d")
+    cores = _cores(g, "r8_", 5)
+    N = 300_001
+    pts = F.bs5_query_points(N, seed=23)
+    one = ChebyshevTT.from_coeff_cores(cores, F.BS5_DOMAIN).to_device(0)
+    fan = ChebyshevTT.from_coeff_cores(cores, F.BS5_DOMAIN).to_device(devices=[0, 0])
+    assert len(fan._fanout) == 2
+    assert np.array_equal(fan.eval_batch(pts), one.eval_batch(pts))
+    assert fan.eval(list(pts[5])) == one.eval(list(pts[5]))
+
+
 # ------------------------------------------------------------------ TT-Cross dense steps
 def test_maxvol_and_dct_match_reference():
     g = golden("g6_primitives")

@@ -139,6 +139,31 @@ def test_spline_large_batch_and_empty_pieces(oracle_mod):
 
 
 @pytest.mark.gpu
+def test_spline_near_node_points_on_the_one_launch_path(oracle_mod):
+    """Points within 1e-14 of a node of their piece (node +- 3e-15; the reference switches to the node's slice there,
+    barycentric.py:1039-1043) through the all-pieces-in-one-launch kernel (k_bary_small_pieces), against the
+    oracle, which applies the reference's rule literally."""
+    case = F.SPLINE_CASES["c"]
+    sp = _build(case)
+    rng = np.random.default_rng(11)
+    n = 2048
+    pts = np.column_stack([rng.uniform(lo, hi, n) for lo, hi in case["domain"]])
+    ids = sp.piece_indices(pts)
+    for r in range(n):
+        piece = sp._pieces[int(ids[r])]
+        for k in rng.choice(3, size=1 + r % 2, replace=False):
+            node = piece.nodes[k][rng.integers(1, len(piece.nodes[k]) - 1)]      # interior node: stays inside the piece
+            pts[r, k] = node + (3e-15 if r % 3 else -4e-15) * max(1.0, abs(node))
+    assert np.array_equal(sp.piece_indices(pts), ids)
+    models = [oracle_mod.BaryModel(p.nodes, p.weights, p.diff_matrices, p.tensor_values) for p in sp._pieces]
+    for s in ([0, 0, 0], [1, 0, 0]):
+        ref = oracle_mod.spline_eval_batch(models, sp.knots, sp._shape, pts, s)
+        got = sp.eval_batch(pts, s)
+        assert np.isfinite(got).all()
+        assert_parity(got, ref, 1e-12, f"spline near-node {s}", float("inf"))
+
+
+@pytest.mark.gpu
 def test_spline_device_resident_entry_points_and_skewed_buckets():
     """pcx_spline_eval[_multi]_batch_dev on device-resident points = the host-pointer calls bit for bit;
     a batch that falls into ONE piece (every lane of every wave shares its bucket counter) and a batch
