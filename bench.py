@@ -182,6 +182,15 @@ class Bary5D(Workload):
             return [self.model.vectorized_eval_multi_batch(pts, self.specs)]
         return [self.model.vectorized_eval_batch(pts, s) for s in self.specs]
 
+    def host_outputs(self, n):
+        return [np.empty((n, len(self.specs)) if len(self.specs) > 1 else n)]
+
+    def host_eval_into(self, pts, outs):
+        """The C-ABI host-pointer call straight into caller-owned arrays (what the Python method wraps)."""
+        self._lib.check(self.m.lib.pcx_bary_eval_multi_batch(self.m.handle, self._lib.p_f64(pts), len(pts),
+                                                             self._lib.p_i32(self.spec_block), len(self.specs),
+                                                             self._lib.p_f64(outs[0])), self.m.lib)
+
     def cpu_rates(self, seconds):
         import oracle
         om = oracle.BaryModel(self.model.nodes, self.model.weights, self.model.diff_matrices,
@@ -270,6 +279,13 @@ class TTWork(Workload):
     def host_eval(self, pts):
         return [self.model.eval_batch(pts)]
 
+    def host_outputs(self, n):
+        return [np.empty(n)]
+
+    def host_eval_into(self, pts, outs):
+        self._lib.check(self.t.lib.pcx_tt_eval_batch(self.t.handle, self._lib.p_f64(pts), len(pts),
+                                                     self._lib.p_f64(outs[0])), self.t.lib)
+
     def cpu_rates(self, seconds):
         import oracle
         pts = self.points(0)
@@ -282,11 +298,14 @@ class TTWork(Workload):
             oracle.tt_eval_batch(self.cores, self.domain, pts[:probe])
             rate = probe / (time.perf_counter() - t0)
             sample = int(min(len(pts), max(probe, rate * budget)))
+            # the whole batch is shorter than the time budget on a many-core host: pass over it again
+            passes = max(1, int(round(rate * budget / sample))) if sample == len(pts) else 1
             t0 = time.perf_counter()
-            oracle.tt_eval_batch(self.cores, self.domain, pts[:sample])
+            for _ in range(passes):
+                oracle.tt_eval_batch(self.cores, self.domain, pts[:sample])
             dt = time.perf_counter() - t0
-            return {"value": sample / dt, "unit": "point-evals/s", "cores": oracle.num_threads(), "kind": "port",
-                    "sample": f"first {sample} points of rank 0's batch, {dt:.1f} s"}
+            return {"value": sample * passes / dt, "unit": "point-evals/s", "cores": oracle.num_threads(), "kind": "port",
+                    "sample": f"first {sample} points of rank 0's batch x {passes} pass(es), {dt:.1f} s"}
 
         npn = min(len(pts), 200_000)
         t0 = time.perf_counter()
@@ -602,16 +621,42 @@ def run_rank(args) -> int:
                 "traffic": traffic, "traffic_source": source}
 
     def end_to_end(wl, reps=3):
-        """Host-pointer entry point on rank 0's batch: pageable NumPy in, NumPy out."""
+        """Host-pointer entry point on rank 0's batch: pageable NumPy in, NumPy out; then the same call on arrays the
+        caller page-locked beforehand (pcx_host_register: asynchronous copies at PCIe rate, registration not timed)."""
         pts = np.ascontiguousarray(wl.points(rank))
         wl.host_eval(pts[: min(len(pts), 65536)])                  # staging buffers, derivative tensors
-        wl.host_eval(pts)
+        res = wl.host_eval(pts)
         t0 = time.perf_counter()
         for _ in range(reps):
             wl.host_eval(pts)
         dt = (time.perf_counter() - t0) / reps
-        return {"value": len(pts) * wl.evals_per_point / dt, "unit": "point-evals/s", "ms_per_call": dt * 1e3,
-                "what": "host-pointer C-ABI call on the same batch: pageable H2D + kernel + D2H inclusive"}
+        moved = pts.nbytes + sum(np.asarray(r).nbytes for r in res)
+        out = {"value": len(pts) * wl.evals_per_point / dt, "unit": "point-evals/s", "ms_per_call": dt * 1e3,
+               "pcie_gb_per_s": moved / dt / 1e9,
+               "what": "host-pointer C-ABI call on the same batch: pageable H2D + kernel + D2H inclusive"}
+        if hasattr(wl, "host_eval_into"):
+            try:
+                outs = wl.host_outputs(len(pts))
+                regs = []
+                t0 = time.perf_counter()
+                for a in [pts] + outs:
+                    if lib.pcx_host_register(dev, a.ctypes.data_as(ctypes.c_void_p), a.nbytes) == 0:
+                        regs.append(a)
+                t_reg = time.perf_counter() - t0
+                if len(regs) == 1 + len(outs):
+                    wl.host_eval_into(pts, outs)
+                    t0 = time.perf_counter()
+                    for _ in range(reps):
+                        wl.host_eval_into(pts, outs)
+                    dtp = (time.perf_counter() - t0) / reps
+                    out["page_locked"] = {"value": len(pts) * wl.evals_per_point / dtp, "ms_per_call": dtp * 1e3,
+                                          "pcie_gb_per_s": moved / dtp / 1e9, "register_ms_not_timed": t_reg * 1e3,
+                                          "what": "the same call on caller arrays page-locked once with pcx_host_register"}
+                for a in regs:
+                    lib.pcx_host_unregister(a.ctypes.data_as(ctypes.c_void_p))
+            except Exception as exc:                                 # noqa: BLE001
+                out["page_locked"] = {"error": f"{type(exc).__name__}: {exc}"}
+        return out
 
     def cpu_baseline(wl, seconds):
         c_port, numpy_loop = wl.cpu_rates(seconds)
@@ -640,6 +685,79 @@ def run_rank(args) -> int:
                          "side_stream_ms_per_step": rec["side_ms"]}
             if rec["pinned"] is not None:
                 out[mode]["host_buffer_pinned"] = rec["pinned"]
+        return out
+
+    def config1_companion():
+        """BASELINE config 1 (2-D sin(x)cos(y) on [-1,1]^2, 12 x 12 nodes, 10^4 points, default_rng(1) -- the reference's
+        own CPU-runnable case): the model is built through the Python callback API, then one call =
+        one batch of 10^4 points.  GPU: microseconds per host-pointer call and per device-resident launch; CPU beside
+        it: the C port and the per-point NumPy loop in the reference's shape, microseconds per point."""
+        from pychebyshev_amd import ChebyshevApproximation
+        c = ChebyshevApproximation(lambda x, _=None: math.sin(x[0]) * math.cos(x[1]), 2, [[-1.0, 1.0], [-1.0, 1.0]], [12, 12])
+        t0 = time.perf_counter()
+        c.build(verbose=False)
+        build_s = time.perf_counter() - t0
+        n = 10_000
+        pts = np.random.default_rng(1).uniform(-1.0, 1.0, (n, 2))
+        y = c.vectorized_eval_batch(pts, [0, 0])
+        err = float(np.max(np.abs(y - np.sin(pts[:, 0]) * np.cos(pts[:, 1]))))
+        reps = 300
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            c.vectorized_eval_batch(pts, [0, 0])
+        host_us = (time.perf_counter() - t0) / reps * 1e6
+        m = c._model()
+        d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+        chk(lib.pcx_dev_malloc(dev, pts.nbytes, ctypes.byref(d_pts)))
+        chk(lib.pcx_dev_malloc(dev, n * 8, ctypes.byref(d_out)))
+        chk(lib.pcx_memcpy_h2d(dev, d_pts, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes))
+        st = ctypes.c_void_p()
+        chk(lib.pcx_bary_stream(m.handle, ctypes.byref(st)))
+        spec = _lib.i32([0, 0])
+        for _ in range(10):
+            chk(lib.pcx_bary_eval_batch_dev(m.handle, d_pts, n, _lib.p_i32(spec), d_out, st))
+        a, b = new_event(), new_event()
+        chk(lib.pcx_event_record(a, st))
+        for _ in range(reps):
+            chk(lib.pcx_bary_eval_batch_dev(m.handle, d_pts, n, _lib.p_i32(spec), d_out, st))
+        chk(lib.pcx_event_record(b, st))
+        chk(lib.pcx_stream_synchronize(st))
+        res_us = elapsed_ms(a, b) / reps * 1e3
+        lib.pcx_dev_free(dev, d_pts)
+        lib.pcx_dev_free(dev, d_out)
+        free_events()
+        info = _lib.i32(np.zeros(6))
+        lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
+        out = {"workload": "2D sin(x)cos(y) on [-1,1]^2, n=12x12 barycentric, 10,000 fp64 queries (default_rng(1)), built "
+                           "through the Python callback API", "points_per_call": n, "build_seconds": build_s,
+               "max_abs_error_vs_function": err,
+               "gpu": {"kernel": "k_bary_small<1,12>" if int(info[0]) == 4 else f"variant {int(info[0])}",
+                       "host_pointer_us_per_call": host_us, "host_pointer_point_evals_per_s": n / host_us * 1e6,
+                       "resident_us_per_launch": res_us, "resident_point_evals_per_s": n / res_us * 1e6,
+                       "note": "one call is launch-latency-bound at 10^4 points: 156 FMA and 24 B per point "
+                               "(at 4x10^6 points the same kernel runs 5x10^10 points/s, profiles/r02_bary_rate_probe.txt)"}}
+        if not args.no_cpu_baseline:
+            import oracle
+            om = oracle.BaryModel(c.nodes, c.weights, c.diff_matrices, c.tensor_values)
+            cpu = {}
+            for label, threads in (("c_port_all_cores", usable_cores()), ("c_port_one_core", 1)):
+                oracle.set_num_threads(threads)
+                oracle.bary_eval_batch(om, pts, [0, 0])
+                t0 = time.perf_counter()
+                k = 0
+                while time.perf_counter() - t0 < 1.0:
+                    oracle.bary_eval_batch(om, pts, [0, 0])
+                    k += 1
+                dt = time.perf_counter() - t0
+                cpu[label] = {"us_per_point": dt / (k * n) * 1e6, "point_evals_per_s": k * n / dt, "cores": oracle.num_threads(),
+                              "kind": "port", "sample": f"{k} passes over the 10,000 points, {dt:.1f} s"}
+            t0 = time.perf_counter()
+            oracle.bary_eval_batch_numpy(om, pts, [0, 0])
+            dt = time.perf_counter() - t0
+            cpu["numpy_loop"] = {"us_per_point": dt / n * 1e6, "point_evals_per_s": n / dt, "cores": 1,
+                                 "sample": "the 10,000 points once, per-point NumPy matvec loop in the reference's shape "
+                                           "(barycentric.py:1035-1046)"}
+            out["cpu"] = cpu
         return out
 
     multi = group is not None
@@ -742,6 +860,12 @@ def run_rank(args) -> int:
                     sys.stderr.write(f"bench.py: {name} baseline legs failed: {type(exc).__name__}: {exc}\n")
                     out["baseline_error"] = f"{type(exc).__name__}: {exc}"
             companions[field] = out
+        if world == 1:
+            try:
+                companions["c1"] = config1_companion()
+            except Exception as exc:                     # noqa: BLE001
+                sys.stderr.write(f"bench.py: config 1 companion failed: {type(exc).__name__}: {exc}\n")
+                companions["c1"] = {"error": f"{type(exc).__name__}: {exc}"}
 
     if rank == 0:
         line = {

@@ -1051,6 +1051,16 @@ __global__ void k_slider_sum(const double *__restrict__ vals, long N, int n_slid
     out[p * ostride + ooff] = r;
 }
 
+// out[p * ostride + ooff + j] = src[p * w + j], j < w: a group of spec columns into its place in a wider result
+__global__ void k_scatter_columns(const double *__restrict__ src, long N, int w, double *__restrict__ out, long ostride,
+                                  long ooff) {
+    const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= N * w) return;
+    const long p = e / w;
+    const int j = (int)(e - p * w);
+    out[p * ostride + ooff + j] = src[e];
+}
+
 __global__ void k_fill_strided(double *__restrict__ out, long N, long ostride, long ooff, double v) {
     const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (p < N) out[p * ostride + ooff] = v;

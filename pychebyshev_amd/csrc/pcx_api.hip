@@ -1815,8 +1815,27 @@ static int spline_eval_host(pcx_spline *h, const double *pts, int64_t N, const i
 // the per-piece counts on the host, so the call is synchronous: everything has finished when it returns.
 static int spline_eval_dev(pcx_spline *h, const double *d_pts, int64_t N, const int32_t *derivs, int m, double *d_out) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
-    if (N < 0 || m < 1 || m > kMaxSpecs) return fail(PCX_ERR_INVALID, "bad N, or m outside [1, %d]", kMaxSpecs);
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
     if (N > 0 && (!d_pts || !d_out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    if (m > kMaxSpecs) {      // groups of kMaxSpecs specs (as the host-pointer path), each scattered into its columns
+        if (!derivs) return fail(PCX_ERR_INVALID, "derivs is NULL");
+        HIP_TRY(hipSetDevice(h->device));
+        DevBuf part;
+        int rc = part.alloc((size_t)std::max<int64_t>(N, 1) * kMaxSpecs * sizeof(double));
+        if (rc) return rc;
+        for (int s0 = 0; s0 < m; s0 += kMaxSpecs) {
+            const int mc = std::min(kMaxSpecs, m - s0);
+            if ((rc = spline_eval_dev(h, d_pts, N, derivs + (size_t)s0 * h->sd.d, mc, part.as<double>()))) return rc;
+            const long cnt = (long)N * mc;
+            if (cnt > 0) {
+                hipLaunchKernelGGL(k_scatter_columns, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream,
+                                   part.as<double>(), (long)N, mc, d_out, (long)m, (long)s0);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(h->stream));
+            }
+        }
+        return PCX_OK;
+    }
     HIP_TRY(hipSetDevice(h->device));
     std::lock_guard<std::mutex> lk(h->mu);
     const int d = h->sd.d;
@@ -2086,6 +2105,8 @@ struct pcx_tt {
     double *d_cores = nullptr;
     std::mutex mu;
     Scratch s_pts, s_out;
+    hipStream_t stream2 = nullptr;   // second staging slot of the host-pointer pipeline (lazy)
+    Scratch s_pts2, s_out2;
     Pinned pin;           // zero-copy staging for small host-pointer batches
 };
 
@@ -2101,7 +2122,9 @@ extern "C" int pcx_tt_destroy(pcx_tt *h) {
     (void)hipFree(h->d_lpp_tab);
     (void)hipFree(h->d_cores);
     h->s_pts.release(); h->s_out.release();
+    h->s_pts2.release(); h->s_out2.release();
     h->pin.release();
+    if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return PCX_OK;
@@ -2497,19 +2520,51 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
         memcpy(out, h->pin.out, (size_t)N * sizeof(double));
         return PCX_OK;
     }
-    for (int64_t start = 0; start < N; start += kChunkPoints) {
-        long cnt = (long)std::min<int64_t>(kChunkPoints, N - start);
-        int rc = h->s_pts.reserve((size_t)cnt * d * sizeof(double));
+    // The path is transfer-bound (48 .. 88 bytes per point against ~0.1 ns of kernel): pieces of 2^20 points alternate
+    // between two staging slots on two streams, so the upload of piece i+1 runs while piece i is evaluated and piece
+    // i-1 is downloaded (both PCIe directions busy).  From page-locked caller memory (pcx_host_register, or the `pin`
+    // flag of pcx_tt_group_eval_batch) the copies are asynchronous DMA; from pageable memory the driver stages them.
+    const int64_t kTTPipePoints = 1 << 20;
+    const bool piped = N >= 2 * kTTPipePoints;
+    const int64_t chunk = piped ? kTTPipePoints : kChunkPoints;
+    if (piped && !h->stream2) HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    int slot = 0;
+    int64_t prev_start = -1;
+    long prev_cnt = 0;
+    auto download = [&](int sl, int64_t start, long cnt) -> int {
+        const bool second = piped && sl == 1;
+        HIP_TRY(hipMemcpyAsync(out + start, (second ? h->s_out2 : h->s_out).ptr, (size_t)cnt * sizeof(double),
+                               hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
+        return PCX_OK;
+    };
+    for (int64_t start = 0; start < N; start += chunk, slot ^= 1) {
+        long cnt = (long)std::min<int64_t>(chunk, N - start);
+        const bool second = piped && slot == 1;
+        hipStream_t st = second ? h->stream2 : h->stream;
+        Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
+        int rc = sp.reserve((size_t)cnt * d * sizeof(double));
         if (rc) return rc;
-        rc = h->s_out.reserve((size_t)cnt * sizeof(double));
+        if ((rc = so.reserve((size_t)cnt * sizeof(double)))) return rc;
+        HIP_TRY(hipMemcpyAsync(sp.ptr, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
+        rc = tt_launch(h, (const double *)sp.ptr, cnt, (double *)so.ptr, st);
         if (rc) return rc;
-        double *dp = (double *)h->s_pts.ptr, *dout = (double *)h->s_out.ptr;
-        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        rc = tt_launch(h, dp, cnt, dout, h->stream);
-        if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(out + start, dout, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-        HIP_TRY(hipStreamSynchronize(h->stream));
+        if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
+        if (!piped) {                           // single slot: drain before its buffers are reused
+            if ((rc = download(slot, start, cnt))) return rc;
+            HIP_TRY(hipStreamSynchronize(st));
+            prev_start = -1;
+            slot ^= 1;
+            continue;
+        }
+        prev_start = start;
+        prev_cnt = cnt;
     }
+    if (prev_start >= 0) {
+        int rc = download(slot ^ 1, prev_start, prev_cnt);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
     return PCX_OK;
 }
 
@@ -2662,11 +2717,11 @@ extern "C" int pcx_tt_svd(int device, int d, const int32_t *n_nodes, const doubl
         for (int i = 0; i < m; ++i) fro2 += hnorm[i];
         const double eps64 = 8.0 * 2.220446049250313e-16;   // rows below 8 eps ||C||_F: noise
         const double floor2 = eps64 * eps64 * fro2;
-        // pairs of rows that are both under tol times the largest row norm (<= sigma_max) are not rotated
+        // pairs of rows whose squared norms add up to less than (tol * largest row norm)^2 / m are not rotated
         // against each other: see k_rowjacobi_step
         double row_max2 = 0.0;
         for (int i = 0; i < m; ++i) row_max2 = std::max(row_max2, hnorm[i]);
-        const double sig2 = tol * tol * row_max2;
+        const double sig2 = tol * tol * row_max2 / (double)m;
         const double rot_tol = std::max(1e-15, 2.0 * 2.220446049250313e-16 * std::sqrt((double)N));
         size_t lds_rows = (size_t)m * N * sizeof(double);
         if (m > 1 && lds_rows <= 144 * 1024) {

@@ -40,12 +40,15 @@ __device__ __forceinline__ double ttsvd_block_sum(double v, double *red) {
 // orthogonal rows of length N is itself ~eps sqrt(N) |a||b| of rounding: the host passes
 // max(1e-15, 2 eps sqrt(N)) -- a fixed 1e-15 kept rotating that noise for sweep after sweep on
 // the wide unfoldings (13 sweeps at N = 1331 instead of 7).
-// sig2: a pair whose rows are BOTH below it (squared norm; (tol * largest row norm)^2, and the largest row
-// norm is a lower bound of sigma_max) is skipped: both rows end below the reference's S > tol S[0] cut
-// (tensor_train.py:673-678) and are dropped, and their mutual orthogonality is nobody's business.  Every
-// row that can be kept is still rotated against every other row, so the kept subspace is exact; a
-// smooth tensor's unfolding has dozens of rows at 1e-9 .. 1e-15 sigma_max that otherwise cost ten
-// sweeps among themselves.  (A row only loses norm when rotated against a larger one.)
+// sig2 = (tol * largest row norm)^2 / m (the largest row norm is a lower bound of sigma_max): a pair whose
+// squared norms ADD UP to less than it is skipped.  Every row in a skipped pair is then below sig2, so all
+// such rows together (at most m) carry less than (tol sigma_max)^2: whatever they would merge into stays
+// below the reference's S > tol S[0] cut (tensor_train.py:673-678) and is dropped -- their mutual
+// orthogonality is nobody's business.  (Round 2 skipped a pair as soon as BOTH rows were below
+// (tol * largest row norm)^2: two nearly parallel rows just under the cut could then hide a singular value
+// just above it.)  Every row that can be kept is still rotated against every other row, so the kept
+// subspace is exact; a smooth tensor's unfolding has dozens of rows at 1e-9 .. 1e-15 sigma_max that
+// otherwise cost ten sweeps among themselves.
 __global__ void __launch_bounds__(TTSVD_THREADS)
 k_rowjacobi_step(double *__restrict__ B, long ldb, int m, long N, double *__restrict__ U,
                  int step, int *__restrict__ rotated, double floor2, double rot_tol, double sig2) {
@@ -69,7 +72,7 @@ k_rowjacobi_step(double *__restrict__ B, long ldb, int m, long N, double *__rest
     bb = ttsvd_block_sum(bb, red);
     ab = ttsvd_block_sum(ab, red);
     if (!(aa > floor2) || !(bb > floor2)) return;
-    if (aa < sig2 && bb < sig2) return;      // two rows far below the truncation threshold: both will be dropped
+    if (aa + bb < sig2) return;              // far below the truncation threshold even merged: both will be dropped
     if (ab * ab <= (rot_tol * rot_tol) * aa * bb) return;          // |a.b| <= rot_tol |a||b| without two square roots
     // rotated[1] counts the pairs that were further than 1e-8 from orthogonal: a sweep without any leaves
     // every pair below ~1e-16 (the iteration converges quadratically), so it is the last one -- no extra
@@ -146,7 +149,7 @@ k_rowjacobi_lds(double *__restrict__ Bg, int m, int N, double *__restrict__ Ug, 
                     ab += __shfl_xor(ab, o, 16);
                 }
                 if (!(aa > floor2) || !(bb > floor2)) continue;
-                if (aa < sig2 && bb < sig2) continue;
+                if (aa + bb < sig2) continue;
                 if (ab * ab <= (rot_tol * rot_tol) * aa * bb) continue;
                 const bool large = ab * ab > 1e-16 * aa * bb;
                 const double zeta = (bb - aa) / (2.0 * ab);

@@ -415,11 +415,10 @@ class ChebyshevSpline(ErgonomicsMixin, DerivativeIdMixin):
         out = DeviceArray.empty((n,) if flat else (n, m), s.device)
         if n == 0:
             return out
-        if m <= 64:
-            _lib.check(s.lib.pcx_spline_eval_multi_batch_dev(s.handle, ctypes.c_void_p(dev_pts.ptr), n, _lib.p_i32(specs), m,
-                                                             ctypes.c_void_p(out.ptr)), s.lib)
-            return out
-        raise ValueError("device-resident spline batches take at most 64 derivative specs per call")
+        # any number of specs: the library evaluates them in groups of 64 (as it does for host-pointer batches)
+        _lib.check(s.lib.pcx_spline_eval_multi_batch_dev(s.handle, ctypes.c_void_p(dev_pts.ptr), n, _lib.p_i32(specs), m,
+                                                         ctypes.c_void_p(out.ptr)), s.lib)
+        return out
 
     def piece_indices(self, points) -> np.ndarray:
         """Flat piece index of every point, computed on the device (diagnostic)."""

@@ -411,6 +411,32 @@ def test_tt_svd_value_cores_reproduce_the_tensor_and_are_orthonormal():
     assert np.allclose(s, s_ref, rtol=1e-12, atol=0)
 
 
+def test_tt_svd_keeps_a_singular_value_hidden_in_nearly_parallel_small_rows():
+    """two nearly parallel rows, each just BELOW tol x the largest row norm, combine into a singular value
+    just ABOVE tol S[0]: the reference's rule (count S > tol S[0], tensor_train.py:673-678) keeps it.  Round 2's
+    Jacobi iteration skipped the pair (both rows "will be dropped") and lost the rank; the skip rule now needs the
+    pair's norms to ADD UP to less than (tol x largest row norm)^2 / rows.  Both a wide unfolding (global-memory
+    iteration) and a small one (LDS iteration)."""
+    rng = np.random.default_rng(12)
+    tol = 1e-6
+    for shape in ((3, 40, 40), (3, 4, 5)):
+        n_rest = shape[1] * shape[2]
+        u = rng.standard_normal(n_rest)
+        u /= np.linalg.norm(u)
+        v = rng.standard_normal(n_rest)
+        v -= u * (u @ v)
+        v /= np.linalg.norm(v)
+        w = rng.standard_normal(n_rest)
+        w -= u * (u @ w) + v * (v @ w)
+        w /= np.linalg.norm(w)
+        C = np.vstack([u, 0.8 * tol * v, 0.8 * tol * (v + 1e-3 * w) / np.linalg.norm(v + 1e-3 * w)])
+        S = np.linalg.svd(C, compute_uv=False)
+        want = int(np.sum(S > tol * S[0]))
+        assert want == 2 and S[1] > 1.1 * tol                       # the case the advice describes
+        cores = tt_mod._tt_svd_from_tensor(C.reshape(shape), max_rank=3, tol=tol)
+        assert cores[0].shape[2] == want, (shape, cores[0].shape)
+
+
 def test_build_method_svd_matches_reference(capsys):
     g = golden("g12_tt_svd")
     cases = {

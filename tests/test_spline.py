@@ -210,6 +210,14 @@ def test_spline_device_resident_entry_points_and_skewed_buckets():
         lib.pcx_dev_free(0, d_out)
     assert lib.pcx_spline_eval_batch_dev(s.handle, None, 5, None, None) < 0
     assert lib.pcx_spline_eval_batch_dev(s.handle, None, 0, None, None) == 0
+    # more specs than one launch takes (64): the device-resident call splits them into groups like the host-pointer
+    # call does (it used to fail with a DeviceArray and succeed with a NumPy array)
+    from pychebyshev_amd.device import DeviceArray
+    many = [[a, b, c] for a in range(3) for b in range(3) for c in range(3)] * 3          # 81 specs
+    small = pts[:2000]
+    hm = sp.eval_multi_batch(small, many)
+    dm = sp.eval_multi_batch(DeviceArray.from_host(small), many)
+    assert hm.shape == (2000, 81) and np.array_equal(dm.to_host(), hm)
 
 
 @pytest.mark.gpu
