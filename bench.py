@@ -87,6 +87,27 @@ def bs_5d(x, _=None):
     return S * math.exp(-BS_Q * T) * ncdf(d1) - K * math.exp(-r * T) * ncdf(d1 - sq)
 
 
+def count_gemms(specs, span=1):
+    """GEMMs one multi-spec step executes: specs with equal orders along dimensions 1.. and dim-0 orders within
+    [base, base + span] share one (the library's grouping rule, pcx_bary_set_group_span)."""
+    if span <= 0:
+        return len(specs)
+    by_key = {}
+    for s in specs:
+        by_key.setdefault(tuple(s[1:]), []).append(s[0])
+    total = 0
+    for orders in by_key.values():
+        orders = sorted(orders)
+        i = 0
+        while i < len(orders):
+            e = i
+            while e < len(orders) and orders[e] <= orders[i] + span:
+                e += 1
+            total += 1
+            i = e
+    return total
+
+
 def uniform_points(domain, n, seed):
     """One rng.uniform(lo, hi, n) per dimension, stacked column-wise (the reference's recipe)."""
     rng = np.random.default_rng(seed)
@@ -147,7 +168,7 @@ class Bary5D(Workload):
         self.spec_arrays = [lib_mod.i32(s) for s in self.specs]
         self.spec_block = lib_mod.i32(np.asarray(self.specs).reshape(-1))
         # GEMMs a step executes: specs that differ by one order along dimension 0 share one (span 1: price + delta)
-        self.gemms_per_step = len(self.specs)
+        self.gemms_per_step = count_gemms(self.specs, 1) if n_points >= 65536 else len(self.specs)
 
     def points(self, rank):
         return uniform_points(BS5_DOMAIN, self.points_per_gpu, 99 + rank)
@@ -778,14 +799,20 @@ def run_rank(args) -> int:
 
     def companion(name):
         cwl = make_workload(_lib, name, 0)
-        if name == "greeks5d":
-            cwl.gemms_per_step = 5          # span 1 (default): price + delta share one slab GEMM, 4 specs keep their own
-        rec = measure(cwl, args.steps, args.warmup, headline_mode)
+        # a TT step is 0.9 ms (3 ms for the 10-D model): 20 of them end inside the clock transient that follows the
+        # start of a power-limited FP64 kernel stream (the first launches run ~6 % fast, the next ~10 % slow, steady
+        # after ~30 ms: profiles/r03_tt5d_dispatch_times.txt).  The TT companions therefore warm up and time longer.
+        c_steps, c_warm = args.steps, args.warmup
+        if name == "tt5d":
+            c_steps, c_warm = max(args.steps, 200), max(args.warmup, 50)
+        elif name == "tt10d":
+            c_steps, c_warm = max(args.steps, 60), max(args.warmup, 15)
+        rec = measure(cwl, c_steps, c_warm, headline_mode)
         if rank != 0 and name != "greeks5d":
             return None
         out = {"workload": cwl.name, "points_per_gpu_per_step": cwl.points_per_gpu,
-               "evals_per_point": cwl.evals_per_point, "value": rate(cwl, rec, args.steps),
-               "unit": "point-evals/s", "ms_per_step": rec["elapsed"] / args.steps * 1e3,
+               "evals_per_point": cwl.evals_per_point, "value": rate(cwl, rec, c_steps),
+               "unit": "point-evals/s", "ms_per_step": rec["elapsed"] / c_steps * 1e3, "steps": c_steps, "warmup": c_warm,
                "roofline": roofline_of(cwl, rec)}
         if name == "greeks5d":
             out["roofline"]["flop_basis"] = ("EXECUTED GEMMs: 5 per step for 6 specs (price and delta share one slab-packed "
@@ -793,6 +820,7 @@ def run_rank(args) -> int:
             out["config"] = {"group_span": 1, "gemms_per_step": 5,
                              "parity": "every spec within 1e-12 (normwise) of the reference's batch results"}
             # the same step with gamma folded into the price/delta GEMM (span 2) and with no sharing (span 0)
+            assert cwl.gemms_per_step == 5
             for span, gemms, key, note in ((2, 4, "span2", "price + delta + gamma share one GEMM: gamma 4.4e-12 from the "
                                                            "reference's batch path (outside the 1e-12 bar; opt-in)"),
                                            (0, 6, "span0", "no sharing: one GEMM per spec (round 2's path)")):

@@ -104,7 +104,7 @@ def tt_case(rng, stats):
                 1e-300)
     t = tt._dev()
     fails = []
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4):
         if variant and t.lib.pcx_tt_set_kernel(t.handle, variant) != 0:
             continue
         got = tt.eval_batch(pts)
@@ -182,6 +182,49 @@ def multi_case(rng, stats):
     return fails
 
 
+def group_case(rng, stats):
+    """Dim-0 groups of large multi-spec batches (round 3): a 3..5-D tensor whose MFMA plan admits slab packing,
+    N >= 65,536, specs sharing their orders along dimensions 1.. and one dim-0 order apart (plus strays that keep
+    their own GEMM) -- every column of a 3,000-row sample against the oracle.  Half the tensors are smooth
+    (the hard case for differentiating after the contraction), half are noise."""
+    d = int(rng.integers(3, 6))
+    n0 = int(rng.integers(3, 14))
+    rest = [int(rng.integers(4, 13 if d == 3 else (9 if d == 4 else 7))) for _ in range(d - 1)]
+    shape = [n0] + rest
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-3, 3, d), rng.uniform(0.5, 4, d))]
+    if rng.random() < 0.5:
+        T = rng.standard_normal(shape)
+        kind = "noise"
+    else:
+        grid = np.meshgrid(*[np.linspace(lo, hi, k) for (lo, hi), k in zip(dom, shape)], indexing="ij")
+        w = rng.uniform(0.2, 1.2, d)
+        T = np.exp(-0.1 * sum(wk * g for wk, g in zip(w, grid))) + np.sin(sum(wk * g for wk, g in zip(w[::-1], grid))) + 3.0
+        kind = "smooth"
+    c = ChebyshevApproximation.from_values(T, d, dom, shape, max_derivative_order=3)
+    key = [int(v) for v in rng.integers(0, 2, d - 1)]
+    base = int(rng.integers(0, 2))
+    specs = [[base] + key, [base + 1] + key, [int(v) for v in rng.integers(0, 2, d)], [base] + key]
+    if rng.random() < 0.5:
+        specs.insert(1, [0] + [int(v) for v in rng.integers(0, 2, d - 1)])
+    npts = 65536 + int(rng.integers(0, 700))
+    pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+    pts[0] = [c.nodes[k][-1] for k in range(d)]
+    pts[1, 0] = c.nodes[0][0]
+    got = c.vectorized_eval_multi_batch(pts, specs)
+    om = oracle.BaryModel(c.nodes, c.weights, c.diff_matrices, c.tensor_values)
+    rows = np.r_[0:64, rng.choice(npts, 2936, replace=False)]
+    fails = []
+    for j, s in enumerate(specs):
+        ref = oracle.bary_eval_batch(om, pts[rows], s)
+        scale = max(float(np.max(np.abs(ref))), 1e-300)
+        err = float(np.max(np.abs(got[rows, j] - ref))) / scale if np.isfinite(got[:, j]).all() else float("inf")
+        stats["group_launches"] = stats.get("group_launches", 0) + 1
+        stats["group_worst"] = max(stats.get("group_worst", 0.0), err)
+        if not err <= 1e-12:
+            fails.append(f"group {kind} shape={shape} dom={dom} specs={specs} col={j} N={npts} err={err:.3e}")
+    return fails
+
+
 def slider_case(rng, stats):
     """Random slider (2..6 dimensions, groups of 1..3, built through the Python callback): the device sum
     against pivot + sum(oracle slide - pivot) in the reference's order, a single-slide derivative against the
@@ -240,7 +283,8 @@ def slider_case(rng, stats):
     return fails
 
 
-KINDS = {"bary": bary_case, "tt": tt_case, "spline": spline_case, "multi": multi_case, "slider": slider_case}
+KINDS = {"bary": bary_case, "tt": tt_case, "spline": spline_case, "multi": multi_case, "slider": slider_case,
+         "group": group_case}
 
 
 def main():
@@ -257,7 +301,7 @@ def main():
         seed = seed0 + cases
         rng = np.random.default_rng(seed)
         try:
-            kind = args.kind or ("bary", "tt", "bary", "tt", "spline", "multi", "slider")[cases % 7]
+            kind = args.kind or ("bary", "tt", "bary", "tt", "spline", "multi", "slider", "group")[cases % 8]
             fails = KINDS[kind](rng, stats)
         except Exception as exc:                       # noqa: BLE001 -- an exception is a finding too
             fails = [f"exception {type(exc).__name__}: {exc}"]
@@ -275,7 +319,8 @@ def main():
           f"{stats.get('spline_launches', 0)} spline evaluations against the oracle, {stats.get('multi_launches', 0)} multi-spec columns "
           f"against single-spec calls; worst error / scale: barycentric {stats['bary_worst']:.2e}, TT {stats['tt_worst']:.2e}, "
           f"spline {stats.get('spline_worst', 0.0):.2e}, multi-spec {stats.get('multi_worst', 0.0):.2e}, "
-          f"slider {stats.get('slider_worst', 0.0):.2e} over {stats.get('slider_launches', 0)} sliders (bar 1e-12); "
+          f"slider {stats.get('slider_worst', 0.0):.2e} over {stats.get('slider_launches', 0)} sliders, dim-0 groups "
+          f"{stats.get('group_worst', 0.0):.2e} over {stats.get('group_launches', 0)} columns (bar 1e-12); "
           f"failures: {len(failures)}")
     return 1 if failures else 0
 

@@ -28,6 +28,18 @@ def counters(path, kernel_substr):
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
+def dispatch_times(kt_dir, kernel_substr, grid_points=None):
+    """Durations (ns) of the dispatches of kernels whose name contains `kernel_substr`, in launch order, from the
+    per-dispatch kernel trace (rocprofv3 --kernel-trace writes *_kernel_trace.csv next to the --stats summary)."""
+    rows = []
+    for f in glob.glob(os.path.join(kt_dir, "**", "*kernel_trace.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if kernel_substr in r["Kernel_Name"]:
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--round", default="r01")
@@ -40,6 +52,14 @@ def main():
     ap.add_argument("--sq")
     ap.add_argument("--sq2", help="optional second SQ pass (instruction mix, LDS)")
     ap.add_argument("--tag", default="", help="suffix for the output names, e.g. _v3")
+    ap.add_argument("--warmup", type=int, default=2, help="untimed warm-up steps of the profiled bench command")
+    ap.add_argument("--launches-per-step", type=int, default=1, help="dispatches of the kernel per bench step")
+    ap.add_argument("--units-per-step", type=int, default=0,
+                    help="roofline units (GEMMs) one step executes when they differ from its dispatches: the Greeks step is "
+                         "2 dispatches (4 specs in one launch with grid.z = 4, + the slab GEMM of price and delta) = 5 GEMMs; "
+                         "durations are then summed per step and divided by this")
+    ap.add_argument("--flop-per-launch", type=float, default=0.0,
+                    help="algorithmic flop of one launch (SURVEY 8d per-point figure x points): adds roofline fractions")
     ap.add_argument("--out", default="", help="output directory (default: <repo>/profiles)")
     a = ap.parse_args()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -51,16 +71,39 @@ def main():
         for f in glob.glob(os.path.join(a.kt, "*kernel_stats.csv")):
             shutil.copyfile(f, os.path.join(out, f"{tag}_kernel_stats.csv"))
             for r in csv.DictReader(open(f)):
-                if a.kernel in r["Name"]:
+                if a.kernel in r["Name"] and "kernel_trace" not in summary:
                     summary["kernel_trace"] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]),
                                                "min_ns": float(r["MinNs"]), "max_ns": float(r["MaxNs"]),
-                                               "percentage": float(r["Percentage"])}
+                                               "percentage": float(r["Percentage"]),
+                                               "note": "rocprofv3 --stats row, ALL dispatches incl. warm-up"}
+        # the timed steps only: drop the dispatches of the warm-up steps (first touches, clock ramp), then median / min
+        rows = dispatch_times(a.kt, a.kernel)
+        skip = a.warmup * a.launches_per_step
+        if len(rows) > skip:
+            timed = [d for _, d, _ in rows[skip:]]
+            if a.units_per_step:
+                L = a.launches_per_step
+                timed = [sum(timed[i:i + L]) / a.units_per_step for i in range(0, len(timed) - L + 1, L)]
+            timed_sorted = sorted(timed)
+            med = timed_sorted[len(timed) // 2] if len(timed) % 2 else 0.5 * (timed_sorted[len(timed) // 2 - 1] + timed_sorted[len(timed) // 2])
+            st = {"dispatches": len(timed) if not a.units_per_step else len(timed) * a.launches_per_step,
+                  "units_per_step": a.units_per_step or None, "warmup_dispatches_dropped": skip, "avg_ns": sum(timed) / len(timed),
+                  "median_ns": med, "min_ns": timed_sorted[0], "max_ns": timed_sorted[-1],
+                  "kernels": sorted({k for _, _, k in rows[skip:]})}
+            if a.flop_per_launch:
+                st["algorithmic_flop_per_launch"] = a.flop_per_launch
+                for key in ("median_ns", "avg_ns", "min_ns"):
+                    st["frac_of_78.6_TFLOPs_at_" + key[:-3]] = a.flop_per_launch / (st[key] * 1e-9) / 78.6e12
+            summary["timed_steps"] = st
     if a.fetch and a.write:
         fs = counters(a.fetch, a.kernel).get("FETCH_SIZE")
         ws = counters(a.write, a.kernel).get("WRITE_SIZE")
         if fs and ws:
             fetch_b = fs[0] * 1024 * 2      # gfx950: FETCH_SIZE reports half of a coalesced stream
             write_b = ws[0] * 1024
+            if a.units_per_step:            # per roofline unit (GEMM), not per dispatch: the step's dispatches summed
+                fetch_b *= a.launches_per_step / a.units_per_step
+                write_b *= a.launches_per_step / a.units_per_step
             summary["hbm"] = {"FETCH_SIZE_KiB_raw": fs[0], "WRITE_SIZE_KiB_raw": ws[0],
                               "fetch_bytes_corrected": fetch_b, "write_bytes": write_b,
                               "hbm_bytes_per_launch": fetch_b + write_b, "dispatches_averaged": fs[1]}
@@ -80,6 +123,8 @@ def main():
             summary["mfma_util_percent"] = 100.0 * sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024)
             if "kernel_trace" in summary:
                 summary["effective_clock_ghz"] = sq["GRBM_GUI_ACTIVE"] / 8 / summary["kernel_trace"]["avg_ns"]
+        if "SQ_INSTS_VALU" in sq and a.points:
+            summary["valu_instructions_per_64_points"] = sq["SQ_INSTS_VALU"] / (a.points / 64.0)
     if a.sq2 and os.path.isdir(a.sq2):
         c = counters(a.sq2, a.kernel)
         if c:
