@@ -752,7 +752,7 @@ def run_rank(args) -> int:
         out = {"workload": "2D sin(x)cos(y) on [-1,1]^2, n=12x12 barycentric, 10,000 fp64 queries (default_rng(1)), built "
                            "through the Python callback API", "points_per_call": n, "build_seconds": build_s,
                "max_abs_error_vs_function": err,
-               "gpu": {"kernel": "k_bary_small<1,12>" if int(info[0]) == 4 else f"variant {int(info[0])}",
+               "gpu": {"kernel": {4: "k_bary_small<1,12>", 5: "k_bary_sq<12,0>"}.get(int(info[0]), f"variant {int(info[0])}"),
                        "host_pointer_us_per_call": host_us, "host_pointer_point_evals_per_s": n / host_us * 1e6,
                        "resident_us_per_launch": res_us, "resident_point_evals_per_s": n / res_us * 1e6,
                        "note": "one call is launch-latency-bound at 10^4 points: 156 FMA and 24 B per point "

@@ -146,7 +146,9 @@ int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const do
 /* Kernel selection and introspection.  variant: 0 = auto, 1 = row-parallel VALU kernel
  * (any shape), 2 = MFMA kernel (v_mfma_f64_16x16x4_f64), 3 = the same contraction on
  * v_mfma_f64_4x4x4_4b_f64 with LDS-staged tiles (bit-identical to 2; opt-in, never picked
- * by auto), 4 = lane-per-point kernel for small tensors (d <= 4, last dimension <= 64 nodes;
+ * by auto), 5 = lane-per-point kernel for mid-size tensors whose last two dimensions have the same node count
+ * (4 .. 24 or 32; d <= 4: both trailing weight vectors in registers, what auto picks there above 4096 elements),
+ * 4 = lane-per-point kernel for small tensors (d <= 4, last dimension <= 64 nodes;
  * what auto picks up to 4096 elements; it sums in the reference's own nesting order and
  * forms the barycentric weights from prefix / suffix products, one division per dimension).
  * PCX_ERR_UNSUPPORTED when the shape is not covered.  info_out receives

@@ -865,6 +865,103 @@ k_bary_small(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes
                                pts, out, valid, row, ostride, ooff, lds + lane);
 }
 
+// ---------------------------------------------------------------------------------
+// K1+K2, lane-per-point form for MID-SIZE tensors whose last two dimensions have the same node count NL
+// (n^3, n^4, a x n x n ...; round 3).  k_bary_small keeps every outer dimension's weights in a per-wave LDS
+// table (sum of outer n x 512 B: 21 KB for 21^3, i.e. < 2 waves per SIMD) and sums a row in ONE dependent
+// FMA chain, so neither other waves nor independent instructions hide the scalar-load latency of the tensor
+// (0.3 .. 0.4 of the FP64 peak on 16^3 .. 40^3; the MFMA kernel's short plans are no better there: 5 .. 10
+// k-steps per row tile against the tile's head-weight look-ups).  Here, as in k_tt_eval_lpp:
+//   * the weights of BOTH trailing dimensions live in registers (b1[NL], b2[NL]); only the leading dimensions'
+//     weights go through LDS (one read per NL x NL block) -> 10 KB per wave for 21^3, 3 .. 4 waves per SIMD;
+//   * an NL x NL block is straight-line code: rows four at a time (four independent chains), every tensor
+//     element a scalar operand of one v_fma_f64 (NL^2 + NL FMAs per block: the reference's own nesting,
+//     barycentric.py:1036-1046, and its FMA count);
+//   * leading dimensions (at most two: d <= 4) are run-time loops around the block.
+// 64 threads per workgroup; dynamic LDS = (sum of leading n) * 64 * 8 bytes.
+// ---------------------------------------------------------------------------------
+template <int NL>
+__device__ __forceinline__ double bary_sq_block(pcx_cptr Tb, const double (&b1)[NL], const double (&b2)[NL]) {
+    // rows per pass: four independent chains, or three / five when that leaves no ragged last pass (a single row is
+    // one dependent chain of NL FMAs: 21^3 ran at 0.375 of the peak with 5 x 4 + 1 rows, against 0.46 for 20^3)
+    constexpr int R4 = (NL % 4 == 0) ? 4 : (NL % 3 == 0) ? 3 : (NL % 5 == 0) ? 5 : (NL % 4 == 1 && NL > 5) ? 3 : 4;
+    double t0 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int i = 0; i < NL; i += R4) {
+        double s[R4];
+#pragma unroll
+        for (int r = 0; r < R4; ++r)
+            if (i + r < NL) s[r] = Tb[(i + r) * NL] * b2[0];
+#pragma unroll
+        for (int k = 1; k < NL; ++k)
+#pragma unroll
+            for (int r = 0; r < R4; ++r)
+                if (i + r < NL) s[r] = __builtin_fma(Tb[(i + r) * NL + k], b2[k], s[r]);
+#pragma unroll
+        for (int r = 0; r < R4; ++r)
+            if (i + r < NL) {
+                if (r & 1) t1 = __builtin_fma(b1[i + r], s[r], t1);
+                else t0 = __builtin_fma(b1[i + r], s[r], t0);
+            }
+    }
+    return t0 + t1;
+}
+
+template <int NL, int LEAD>
+__device__ __forceinline__ double bary_sq_tensor(const BaryDims &dims, pcx_cptr T, const double *bw_lane,
+                                                 const double (&b1)[NL], const double (&b2)[NL]) {
+    if constexpr (LEAD == 0) return bary_sq_block<NL>(T, b1, b2);
+    else if constexpr (LEAD == 1) {
+        double y = 0.0;
+        for (int i0 = 0; i0 < dims.n[0]; ++i0, T += NL * NL)
+            y = __builtin_fma(bw_lane[(size_t)i0 * 64], bary_sq_block<NL>(T, b1, b2), y);
+        return y;
+    } else {
+        double y = 0.0;
+        const double *w1 = bw_lane + (size_t)dims.off[1] * 64;
+        for (int i0 = 0; i0 < dims.n[0]; ++i0) {
+            double a = 0.0;
+            for (int i1 = 0; i1 < dims.n[1]; ++i1, T += NL * NL)
+                a = __builtin_fma(w1[(size_t)i1 * 64], bary_sq_block<NL>(T, b1, b2), a);
+            y = __builtin_fma(bw_lane[(size_t)i0 * 64], a, y);
+        }
+        return y;
+    }
+}
+
+template <int NL, int LEAD>
+__global__ void __launch_bounds__(64)
+k_bary_sq(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, const double *__restrict__ nodes,
+          const double *__restrict__ wts, const double *__restrict__ T, const double *const *__restrict__ T_tab, int m,
+          const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
+          const int *__restrict__ perm) {
+    extern __shared__ double lds[];
+    constexpr int D = LEAD + 2;
+    const int lane = threadIdx.x;
+    const long pidx = (long)blockIdx.x * 64 + lane;
+    const bool valid = pidx < N;
+    const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
+    const pcx_cptr csn = pcx_as_constant(snodes), cnd = pcx_as_constant(nodes), cw = pcx_as_constant(wts);
+    double *bw_lane = lds + lane;
+#pragma unroll
+    for (int k = 0; k < LEAD; ++k) {
+        const double x = valid ? pts[row * D + k] : cnd[dims.off[k]];
+        bary_weights_prod(x, sc.s[k], csn + dims.off[k], cw + dims.off[k], dims.n[k], bw_lane + (size_t)dims.off[k] * 64, 64);
+    }
+    double b1[NL], b2[NL];
+    {
+        const double x1 = valid ? pts[row * D + LEAD] : cnd[dims.off[LEAD]];
+        const double x2 = valid ? pts[row * D + LEAD + 1] : cnd[dims.off[LEAD + 1]];
+        bary_weights_reg<NL, true>(x1, sc.s[LEAD], csn + dims.off[LEAD], cw + dims.off[LEAD], NL, b1);
+        bary_weights_reg<NL, true>(x2, sc.s[LEAD + 1], csn + dims.off[LEAD + 1], cw + dims.off[LEAD + 1], NL, b2);
+    }
+    // the table is wave-private (one wave per workgroup): no barrier
+    for (int z = 0; z < m; ++z) {
+        const double y = bary_sq_tensor<NL, LEAD>(dims, pcx_as_constant(T_tab ? T_tab[z] : T), bw_lane, b1, b2);
+        if (valid) out[row * ostride + ooff + z] = y;
+    }
+}
+
 // All pieces of a piecewise interpolant in ONE launch (pieces of equal shape on the lane-per-point kernel):
 // a launch per piece is launch-bound once a spline has tens of pieces (64 pieces x 15 k points: 0.46 ms even
 // fanned over four streams).  Workgroup b serves 64 consecutive slots of piece blk_piece[b]'s bucket, starting

@@ -314,6 +314,9 @@ struct pcx_bary {
     BarySmallScale small_scale;      // its power-of-two coordinate scales and the nodes times them
     double *d_snodes = nullptr;
     bool small_preferred = false;    // auto picks it (few row tiles: the MFMA kernel would be all prologue)
+    int sq_nl = 0;                   // k_bary_sq (last two dimensions of sq_nl nodes each, d <= 4): 0 = not available
+    bool sq_preferred = false;       // auto picks it
+    bool in_spline = false;          // a piece of a pcx_spline: small pieces stay on k_bary_small (all pieces in one launch)
     int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b, 4 lane-per-point (small tensors)
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
@@ -516,6 +519,18 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
             for (int v : kNlp)
                 if (v >= nl) { h->small_nlp = v; break; }
             h->small_preferred = total <= kSmallTensorElems && nl <= 48;
+            // mid-size tensors with equal trailing node counts: both trailing weight vectors in registers (k_bary_sq)
+            if (d >= 2 && n_nodes[d - 2] == nl && ((nl >= 4 && nl <= 24) || nl == 32) &&
+                (outer_rows - nl) * 64 * (long)sizeof(double) <= 48 * 1024) {
+                h->sq_nl = nl;
+                static const bool sq_auto = [] { const char *e = getenv("PCX_BARY_SQ"); return !(e && e[0] == '0'); }();
+                // tools/bary_rate_probe.py (profiles/r03_bary_rate_probe.txt): ahead of k_bary_small everywhere it applies
+                // (12^2 +33 %, 8^3 +37 %, 11^3 +44 %, 6^4 +50 %) and of the MFMA kernel's short plans for d <= 3
+                // (17^3 +48 %, 20^3 +11 %, 24^3 +15 %); from 10^4 up the MFMA kernel (K = n^2 >= 100) is ahead
+                // 21 and 23 nodes: hipcc runs out of scalar registers on the odd row length (SGPR spills in the block,
+                // 0.37 / 0.36 of the peak against 0.39 / 0.44 on the MFMA kernel): available, not preferred
+                h->sq_preferred = sq_auto && (d <= 3 || total <= kSmallTensorElems) && nl != 21 && nl != 23;
+            }
             // 2^e ~ 2 / (node span): exact to apply, keeps the prefix / suffix products of the weights in range
             std::vector<double> sn((size_t)sum_n);
             for (int k = 0; k < d; ++k) {
@@ -990,6 +1005,37 @@ static int launch_small(pcx_bary *h, const DerivedTensor &dt, const double *cons
 }
 
 
+template <int NL>
+static int launch_sq_t(pcx_bary *h, const DerivedTensor &dt, const double *const *T_tab, int m, const double *d_pts,
+                       long N, double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
+    const int d = h->dims.d;
+    size_t lds = 0;
+    for (int k = 0; k < d - 2; ++k) lds += (size_t)h->dims.n[k] * 64 * sizeof(double);
+    long blocks = (N + 63) / 64;
+    if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+#define PCX_SQ_GO(LEAD)                                                                                               \
+    hipLaunchKernelGGL((k_bary_sq<NL, LEAD>), dim3((unsigned)blocks), dim3(64), lds, st, h->dims, h->small_scale,    \
+                       h->d_snodes, h->d_nodes, h->d_wts, dt.plain, T_tab, m, d_pts, d_out, N, ostride, ooff, perm)
+    if (d == 2) PCX_SQ_GO(0);
+    else if (d == 3) PCX_SQ_GO(1);
+    else PCX_SQ_GO(2);
+#undef PCX_SQ_GO
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+static int launch_sq(pcx_bary *h, const DerivedTensor &dt, const double *const *T_tab, int m, const double *d_pts,
+                     long N, double *d_out, long ostride, long ooff, hipStream_t st, const int *perm) {
+    switch (h->sq_nl) {
+#define CASE_NL(v) case v: return launch_sq_t<v>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+    CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(7) CASE_NL(8) CASE_NL(9) CASE_NL(10) CASE_NL(11) CASE_NL(12) CASE_NL(13)
+    CASE_NL(14) CASE_NL(15) CASE_NL(16) CASE_NL(17) CASE_NL(18) CASE_NL(19) CASE_NL(20) CASE_NL(21) CASE_NL(22)
+    CASE_NL(23) CASE_NL(24) CASE_NL(32)
+#undef CASE_NL
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "square-trailing lane-per-point kernel does not cover this shape");
+}
+
 // ---- dim-0 group launches (BaryG0) --------------------------------------------------------------
 // Slab-packs dt.plain on first use (caller holds h->mu; enqueued on h->stream and synchronised).
 static int bary_pack_g0(pcx_bary *h, DerivedTensor &dt) {
@@ -1050,6 +1096,7 @@ static const long kG0MinPoints = 65536;      // below: per-spec launches (they s
 // the kernel a launch will take: 1 rows, 2 MFMA 16x16x4, 3 MFMA 4x4x4, 4 lane-per-point
 static int bary_effective_variant(const pcx_bary *h) {
     if (h->variant != 0) return h->variant;
+    if (h->sq_nl && h->sq_preferred && !(h->in_spline && h->small_preferred)) return 5;
     return (h->small_nlp && (h->small_preferred || !h->mfma_ok)) ? 4 : (h->mfma_ok ? 2 : 1);
 }
 
@@ -1066,6 +1113,10 @@ static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const doub
     if (variant == 4) {
         if (!h->small_nlp) return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
         return launch_small(h, *dts[0], m > 1 ? frag_tab : nullptr, m, d_pts, N, d_out, ostride, ooff, st, perm);
+    }
+    if (variant == 5) {
+        if (!h->sq_nl) return fail(PCX_ERR_UNSUPPORTED, "square-trailing lane-per-point kernel does not cover this shape");
+        return launch_sq(h, *dts[0], m > 1 ? frag_tab : nullptr, m, d_pts, N, d_out, ostride, ooff, st, perm);
     }
     if (variant == 3) {
         if (!h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
@@ -1199,9 +1250,9 @@ extern "C" int pcx_bary_eval_multi_batch_dev(pcx_bary *h, const double *d_pts, i
         }
         const double *const *frag_tab = dts[0]->slot;
         const int eff = bary_effective_variant(h);
-        if (mc > 1 && (eff == 4 || h->mfma_ok)) {
+        if (mc > 1 && (eff == 4 || eff == 5 || h->mfma_ok)) {
             std::vector<double *> tab(mc);
-            for (int s = 0; s < mc; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
+            for (int s = 0; s < mc; ++s) tab[s] = (eff == 4 || eff == 5) ? dts[s]->plain : dts[s]->frag;
             if (tab != h->tab_host) {
                 HIP_TRY(hipDeviceSynchronize());        // launches still in flight on any stream may read d_tab
                 HIP_TRY(hipMemcpy(h->d_tab, tab.data(), mc * sizeof(double *), hipMemcpyHostToDevice));
@@ -1248,9 +1299,9 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
     }
     const double *const *frag_tab = dts[0]->slot;
     const int eff = bary_effective_variant(h);
-    if (m > 1 && (eff == 4 || h->mfma_ok)) {
+    if (m > 1 && (eff == 4 || eff == 5 || h->mfma_ok)) {
         std::vector<double *> tab(m);
-        for (int s = 0; s < m; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
+        for (int s = 0; s < m; ++s) tab[s] = (eff == 4 || eff == 5) ? dts[s]->plain : dts[s]->frag;
         if (tab != h->tab_host) {   // every earlier launch on this handle has been synchronised
             HIP_TRY(hipMemcpy(h->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));
             h->tab_host = tab;
@@ -1437,8 +1488,9 @@ extern "C" int pcx_tensor_contract_axis(int device, int d, const int32_t *n_node
 
 extern "C" int pcx_bary_set_kernel(pcx_bary *h, int variant) {
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
-    if (variant < 0 || variant > 4) return fail(PCX_ERR_INVALID, "variant %d outside [0, 4]", variant);
+    if (variant < 0 || variant > 5) return fail(PCX_ERR_INVALID, "variant %d outside [0, 5]", variant);
     if (variant == 4 && !h->small_nlp) return fail(PCX_ERR_UNSUPPORTED, "lane-per-point kernel does not cover this shape");
+    if (variant == 5 && !h->sq_nl) return fail(PCX_ERR_UNSUPPORTED, "square-trailing lane-per-point kernel does not cover this shape");
     if (variant == 2 && !h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
     if (variant == 3 && !h->mfma4_ok) return fail(PCX_ERR_UNSUPPORTED, "4x4x4 MFMA kernel does not cover this shape");
     std::lock_guard<std::mutex> lk(h->mu);
@@ -1546,6 +1598,7 @@ extern "C" int pcx_spline_create(int device, int d, const int32_t *n_knots, cons
     if (nk_total > 0 && !knots_cat) { delete h; return fail(PCX_ERR_INVALID, "knots_cat is NULL"); }
     for (int i = 0; i < n_pieces; ++i) {
         if (!pieces[i] || pieces[i]->device != device || pieces[i]->dims.d != d) { delete h; return fail(PCX_ERR_INVALID, "piece %d is NULL, on another device or of another dimension", i); }
+        pieces[i]->in_spline = true;      // small pieces keep k_bary_small: all equal-shape pieces then run in ONE launch
         h->pieces.push_back(pieces[i]);
     }
     h->n_pieces = n_pieces;
@@ -1750,9 +1803,9 @@ static int spline_eval_chunk(pcx_spline *h, const double *dp, long cnt, const in
         }
         const double *const *frag_tab = dts[0]->slot;
         const int eff = bary_effective_variant(pc);
-        if (m > 1 && (eff == 4 || pc->mfma_ok)) {
+        if (m > 1 && (eff == 4 || eff == 5 || pc->mfma_ok)) {
             std::vector<double *> tab(m);
-            for (int s = 0; s < m; ++s) tab[s] = (eff == 4) ? dts[s]->plain : dts[s]->frag;
+            for (int s = 0; s < m; ++s) tab[s] = (eff == 4 || eff == 5) ? dts[s]->plain : dts[s]->frag;
             if (tab != pc->tab_host) {
                 HIP_TRY(hipDeviceSynchronize());            // earlier launches (any stream) may still read d_tab
                 HIP_TRY(hipMemcpy(pc->d_tab, tab.data(), m * sizeof(double *), hipMemcpyHostToDevice));

@@ -745,7 +745,8 @@ def test_lane_per_point_kernel_for_small_tensors(oracle_mod, shape):
     info = _lib.i32(np.zeros(6))
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
-    assert info[0] == (4 if (T.size <= 4096 and shape[-1] <= 48) else 2)
+    sq = d >= 2 and shape[-1] == shape[-2] and (4 <= shape[-1] <= 24 or shape[-1] == 32) and (d <= 3 or T.size <= 4096)
+    assert info[0] == (5 if sq else (4 if (T.size <= 4096 and shape[-1] <= 48) else 2))
     specs = [[0] * d]
     if all(v > 2 for v in shape):
         specs += [[1] + [0] * (d - 1), [0] * (d - 1) + [2]]
@@ -852,3 +853,41 @@ def test_single_process_fan_out_over_device_handles(bs5d):
     out = np.empty(N)
     assert m.lib.pcx_bary_group_eval_multi_batch(harr, 2, _lib.p_f64(pts), N, _lib.p_i32(_lib.i32([0] * 5)), 1,
                                                  _lib.p_f64(out), 0) == _lib.PCX_ERR_INVALID
+
+
+@pytest.mark.parametrize("shape", [(20, 20, 20), (7, 7), (5, 9, 9), (3, 4, 6, 6), (24, 24), (32, 32), (2, 17, 17), (4, 4),
+                                   (13, 13, 13), (6, 5, 11, 11)])
+def test_square_trailing_lane_per_point_kernel(oracle_mod, shape):
+    """k_bary_sq (variant 5, round 3): tensors whose last two dimensions share a node count (4..24, 32), d = 2..4 --
+    both trailing weight vectors in registers, leading weights in LDS, an NL x NL block of straight-line FMAs with the
+    tensor as scalar operands.  Value and derivative specs, multi-spec launches, ragged batches, exact-node and
+    near-node rows (node +- 3e-15: the interpolant at x, within 1e-12 of the reference's node rule) against the
+    oracle; auto picks it above 4096 elements."""
+    rng = np.random.default_rng(7 * sum(shape) + len(shape))
+    d = len(shape)
+    T = rng.standard_normal(shape)
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-5, 5, d), rng.uniform(0.5, 5, d))]
+    c = ChebyshevApproximation.from_values(T, d, dom, list(shape))
+    om = _oracle_model(oracle_mod, c)
+    info = _lib.i32(np.zeros(6))
+    m = c._model()
+    m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
+    assert info[0] == 5                      # d <= 3, or up to 4096 elements: ahead of both other kernels
+    _set_kernel(c, 5)
+    specs = [[0] * d, [1] + [0] * (d - 1), [0] * (d - 1) + [2], [0] * (d - 2) + [1, 1]]
+    for npts in (1, 63, 64, 65, 3000):
+        pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+        pts[0] = [c.nodes[k][-1] for k in range(d)]                 # a grid point
+        if npts > 4:
+            pts[2, d - 1] = c.nodes[d - 1][0]                         # exact node in one register dimension
+            pts[3, d - 2] = c.nodes[d - 2][1] + 3e-15                 # near-node in the other
+            pts[4, 0] = c.nodes[0][-1] - 4e-15 * max(1.0, abs(c.nodes[0][-1]))
+        multi = c.vectorized_eval_multi_batch(pts, specs)
+        for j, s in enumerate(specs):
+            ref = oracle_mod.bary_eval_batch(om, pts, s)
+            got = c.vectorized_eval_batch(pts, s)
+            assert_parity(got, ref, 1e-12, f"sq {shape} {s} N={npts}", float("inf"), floor=np.max(np.abs(T)))
+            assert np.array_equal(multi[:, j], got), (shape, s, npts)
+    assert c.vectorized_eval_batch(pts[:1], [0] * d)[0] == T[tuple([-1] * d)]      # grid point: the tensor entry exactly
+    # a point's value does not depend on the batch it sits in
+    assert np.array_equal(c.vectorized_eval_batch(pts[100:133], specs[0]), c.vectorized_eval_batch(pts, specs[0])[100:133])
