@@ -30,11 +30,15 @@ Also on the JSON line:
                HIP events on the launch stream, vs the FP64 MFMA peak; `traffic` is the
                HBM bytes per launch from the committed PMC profile (cached; see
                traffic_source), not collected in this run.
-  end_to_end   the host-pointer entry point on the same batch (H2D + kernel + D2H).
-  greeks, tt, tt10d
-               companions: config 4 (6 derivative specs), config 3 (TT-Cross build + 10^7-point
-               eval_batch) and config 5's model at a per-GPU batch (10-D, rank 16, 4x10^6 points),
-               same timing discipline, never mixed into `value`.
+  end_to_end   the host-pointer entry point on the same batch (H2D + kernel + D2H), with the PCIe GB/s, and
+               the same call on caller arrays page-locked beforehand (pcx_host_register).
+  greeks, tt, tt10d, c1
+               companions: config 4 (6 derivative specs in ONE multi-spec call: price and delta share a
+               GEMM, roofline on the 5 executed GEMMs; `span2` / `span0` beside it), config 3 (TT-Cross
+               build + 10^7-point eval_batch; 200 timed steps after 50 warm-ups: a 0.8 ms step is
+               inside the FP64 clock transient for the first ~30 ms), config 5's model at a per-GPU
+               batch (10-D, rank 16, 4x10^6 points) and config 1 (12 x 12, 10^4 points: microseconds
+               per call, GPU and CPU) -- same timing discipline, never mixed into `value`.
   cpu_baseline the CPU oracle (C restatement of the reference, OpenMP) on all usable
                host cores, on the per-GPU CPU share (16) and the reference's NumPy shape on
                one core -- bounded samples of the same workload, rank 0, N = 1 only.

@@ -123,12 +123,12 @@ def main():
             summary["mfma_util_percent"] = 100.0 * sq["SQ_VALU_MFMA_BUSY_CYCLES"] / (sq["GRBM_GUI_ACTIVE"] / 8 * 1024)
             if "kernel_trace" in summary:
                 summary["effective_clock_ghz"] = sq["GRBM_GUI_ACTIVE"] / 8 / summary["kernel_trace"]["avg_ns"]
-        if "SQ_INSTS_VALU" in sq and a.points:
-            summary["valu_instructions_per_64_points"] = sq["SQ_INSTS_VALU"] / (a.points / 64.0)
     if a.sq2 and os.path.isdir(a.sq2):
         c = counters(a.sq2, a.kernel)
         if c:
             summary["sq_mix"] = {k: v[0] for k, v in c.items()}
+            if "SQ_INSTS_VALU" in c and a.points:
+                summary["valu_instructions_per_64_points"] = c["SQ_INSTS_VALU"][0] / (a.points / 64.0)
     json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
