@@ -39,6 +39,9 @@ struct TTLppDim {
 #define PCX_LPP_MAX_RANK 16
 #define PCX_LPP_MAX_NODES 16
 #define PCX_LPP_WG 64
+#ifndef PCX_LPP_ONE_CHAIN
+#define PCX_LPP_ONE_CHAIN 0
+#endif
 
 template <int RL, int NJ>
 __device__ __forceinline__ void tt_lpp_body(pcx_lpp_cptr G, int rr, double x, double *vl) {
@@ -60,7 +63,7 @@ __device__ __forceinline__ void tt_lpp_body(pcx_lpp_cptr G, int rr, double x, do
 #pragma unroll
             for (int a = 0; a < RL; ++a) M[a] = __builtin_fma(T[j], G[a * NJ + j], M[a]);
         double s;
-        if constexpr (RL < 4) {
+        if constexpr (RL < 4 || PCX_LPP_ONE_CHAIN) {
             s = v[0] * M[0];
 #pragma unroll
             for (int a = 1; a < RL; ++a) s = __builtin_fma(v[a], M[a], s);
