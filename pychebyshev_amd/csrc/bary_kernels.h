@@ -929,20 +929,13 @@ __device__ __forceinline__ double bary_sq_tensor(const BaryDims &dims, pcx_cptr 
     }
 }
 
+// The body shared by the single-model kernel and the all-pieces-of-a-spline kernel.
 template <int NL, int LEAD>
-__global__ void __launch_bounds__(64)
-k_bary_sq(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, const double *__restrict__ nodes,
-          const double *__restrict__ wts, const double *__restrict__ T, const double *const *__restrict__ T_tab, int m,
-          const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
-          const int *__restrict__ perm) {
-    extern __shared__ double lds[];
+__device__ __forceinline__ void bary_sq_body(const BaryDims &dims, const BarySmallScale &sc, pcx_cptr csn, pcx_cptr cnd, pcx_cptr cw,
+                                             const double *T, const double *const *T_tab, int m, const double *__restrict__ pts,
+                                             double *__restrict__ out, bool valid, long row, long ostride, long ooff,
+                                             double *bw_lane) {
     constexpr int D = LEAD + 2;
-    const int lane = threadIdx.x;
-    const long pidx = (long)blockIdx.x * 64 + lane;
-    const bool valid = pidx < N;
-    const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
-    const pcx_cptr csn = pcx_as_constant(snodes), cnd = pcx_as_constant(nodes), cw = pcx_as_constant(wts);
-    double *bw_lane = lds + lane;
 #pragma unroll
     for (int k = 0; k < LEAD; ++k) {
         const double x = valid ? pts[row * D + k] : cnd[dims.off[k]];
@@ -960,6 +953,21 @@ k_bary_sq(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, c
         const double y = bary_sq_tensor<NL, LEAD>(dims, pcx_as_constant(T_tab ? T_tab[z] : T), bw_lane, b1, b2);
         if (valid) out[row * ostride + ooff + z] = y;
     }
+}
+
+template <int NL, int LEAD>
+__global__ void __launch_bounds__(64)
+k_bary_sq(BaryDims dims, BarySmallScale sc, const double *__restrict__ snodes, const double *__restrict__ nodes,
+          const double *__restrict__ wts, const double *__restrict__ T, const double *const *__restrict__ T_tab, int m,
+          const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
+          const int *__restrict__ perm) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const long pidx = (long)blockIdx.x * 64 + lane;
+    const bool valid = pidx < N;
+    const long row = valid ? (perm ? (long)perm[pidx] : pidx) : 0;
+    bary_sq_body<NL, LEAD>(dims, sc, pcx_as_constant(snodes), pcx_as_constant(nodes), pcx_as_constant(wts), T, T_tab, m, pts, out,
+                           valid, row, ostride, ooff, lds + lane);
 }
 
 // All pieces of a piecewise interpolant in ONE launch (pieces of equal shape on the lane-per-point kernel):
@@ -993,6 +1001,28 @@ k_bary_small_pieces(BaryDims dims, const SplinePieceModel *__restrict__ models, 
     for (int k = 0; k < 4; ++k) sc.s[k] = mp->sc.s[k];
     bary_small_body<DOUT, NLP>(dims, sc, pcx_as_constant(mp->snodes), pcx_as_constant(mp->nodes), pcx_as_constant(mp->wts),
                                mp->T, mp->T_tab, m, pts, out, valid, row, ostride, ooff, lds + lane);
+}
+
+// The same for pieces whose last two dimensions share a node count (k_bary_sq's body).
+template <int NL, int LEAD>
+__global__ void __launch_bounds__(64)
+k_bary_sq_pieces(BaryDims dims, const SplinePieceModel *__restrict__ models, const int *__restrict__ blk_piece,
+                 const int *__restrict__ blk_first, const int *__restrict__ piece_end, int m,
+                 const double *__restrict__ pts, double *__restrict__ out, long ostride, long ooff,
+                 const int *__restrict__ perm) {
+    extern __shared__ double lds[];
+    const int lane = threadIdx.x;
+    const int piece = blk_piece[blockIdx.x];
+    const long pidx = (long)blk_first[blockIdx.x] + lane;
+    const bool valid = pidx < (long)piece_end[piece];
+    const long row = valid ? (long)perm[pidx] : 0;
+    typedef const SplinePieceModel __attribute__((address_space(4))) *model_cptr;
+    const model_cptr mp = (model_cptr)(unsigned long long)(models + piece);
+    BarySmallScale sc;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) sc.s[k] = mp->sc.s[k];
+    bary_sq_body<NL, LEAD>(dims, sc, pcx_as_constant(mp->snodes), pcx_as_constant(mp->nodes), pcx_as_constant(mp->wts), mp->T,
+                           mp->T_tab, m, pts, out, valid, row, ostride, ooff, lds + lane);
 }
 
 // ---------------------------------------------------------------------------------

@@ -316,7 +316,7 @@ struct pcx_bary {
     bool small_preferred = false;    // auto picks it (few row tiles: the MFMA kernel would be all prologue)
     int sq_nl = 0;                   // k_bary_sq (last two dimensions of sq_nl nodes each, d <= 4): 0 = not available
     bool sq_preferred = false;       // auto picks it
-    bool in_spline = false;          // a piece of a pcx_spline: small pieces stay on k_bary_small (all pieces in one launch)
+    bool in_spline = false;          // a piece of a pcx_spline
     int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b, 4 lane-per-point (small tensors)
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
@@ -1096,7 +1096,7 @@ static const long kG0MinPoints = 65536;      // below: per-spec launches (they s
 // the kernel a launch will take: 1 rows, 2 MFMA 16x16x4, 3 MFMA 4x4x4, 4 lane-per-point
 static int bary_effective_variant(const pcx_bary *h) {
     if (h->variant != 0) return h->variant;
-    if (h->sq_nl && h->sq_preferred && !(h->in_spline && h->small_preferred)) return 5;
+    if (h->sq_nl && h->sq_preferred) return 5;
     return (h->small_nlp && (h->small_preferred || !h->mfma_ok)) ? 4 : (h->mfma_ok ? 2 : 1);
 }
 
@@ -1598,17 +1598,17 @@ extern "C" int pcx_spline_create(int device, int d, const int32_t *n_knots, cons
     if (nk_total > 0 && !knots_cat) { delete h; return fail(PCX_ERR_INVALID, "knots_cat is NULL"); }
     for (int i = 0; i < n_pieces; ++i) {
         if (!pieces[i] || pieces[i]->device != device || pieces[i]->dims.d != d) { delete h; return fail(PCX_ERR_INVALID, "piece %d is NULL, on another device or of another dimension", i); }
-        pieces[i]->in_spline = true;      // small pieces keep k_bary_small: all equal-shape pieces then run in ONE launch
+        pieces[i]->in_spline = true;
         h->pieces.push_back(pieces[i]);
     }
     h->n_pieces = n_pieces;
     {   // the one-launch path: every piece the same shape, all on the lane-per-point kernel (PCX_SPLINE_FUSED=0: off)
         const pcx_bary *p0 = h->pieces[0];
         const char *f = getenv("PCX_SPLINE_FUSED");
-        bool ok = n_pieces > 1 && p0->small_nlp > 0 && !(f && f[0] == '0');
+        bool ok = n_pieces > 1 && (p0->small_nlp > 0 || p0->sq_nl > 0) && !(f && f[0] == '0');
         for (int i = 0; ok && i < n_pieces; ++i) {
             const pcx_bary *pc = h->pieces[i];
-            ok = pc->small_nlp == p0->small_nlp && memcmp(&pc->dims, &p0->dims, sizeof(BaryDims)) == 0;
+            ok = pc->small_nlp == p0->small_nlp && pc->sq_nl == p0->sq_nl && memcmp(&pc->dims, &p0->dims, sizeof(BaryDims)) == 0;
         }
         h->fused_ok = ok;
     }
@@ -1687,14 +1687,47 @@ static int launch_small_pieces_d(const pcx_bary *p0, const SplinePieceModel *mod
 
 // All non-empty pieces in one launch.  Returns PCX_OK with *done = false when the batch does not qualify
 // (a piece forced onto another kernel form): the caller then launches per piece.
+template <int NL>
+static int launch_sq_pieces_t(const pcx_bary *p0, const SplinePieceModel *models, const int *blk_piece, const int *blk_first,
+                              const int *piece_end, int m, long blocks, const double *dp, double *dout, const int *perm,
+                              hipStream_t st) {
+    const int d = p0->dims.d;
+    size_t lds = 0;
+    for (int k = 0; k < d - 2; ++k) lds += (size_t)p0->dims.n[k] * 64 * sizeof(double);
+#define PCX_SQP_GO(LEAD)                                                                                              \
+    hipLaunchKernelGGL((k_bary_sq_pieces<NL, LEAD>), dim3((unsigned)blocks), dim3(64), lds, st, p0->dims, models, blk_piece, \
+                       blk_first, piece_end, m, dp, dout, (long)m, 0L, perm)
+    if (d == 2) PCX_SQP_GO(0);
+    else if (d == 3) PCX_SQP_GO(1);
+    else PCX_SQP_GO(2);
+#undef PCX_SQP_GO
+    return PCX_OK;
+}
+
+static int launch_sq_pieces(const pcx_bary *p0, const SplinePieceModel *models, const int *blk_piece, const int *blk_first,
+                            const int *piece_end, int m, long blocks, const double *dp, double *dout, const int *perm,
+                            hipStream_t st) {
+    switch (p0->sq_nl) {
+#define CASE_NL(v) case v: return launch_sq_pieces_t<v>(p0, models, blk_piece, blk_first, piece_end, m, blocks, dp, dout, perm, st);
+    CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(7) CASE_NL(8) CASE_NL(9) CASE_NL(10) CASE_NL(11) CASE_NL(12) CASE_NL(13)
+    CASE_NL(14) CASE_NL(15) CASE_NL(16) CASE_NL(17) CASE_NL(18) CASE_NL(19) CASE_NL(20) CASE_NL(21) CASE_NL(22)
+    CASE_NL(23) CASE_NL(24) CASE_NL(32)
+#undef CASE_NL
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "square-trailing lane-per-point kernel does not cover this piece shape");
+}
+
 static int spline_launch_fused(pcx_spline *h, const double *dp, const std::vector<int> &counts,
                                const std::vector<int> &offsets, const int32_t *derivs, int m, double *dout, bool *done) {
     *done = false;
     if (!h->fused_ok || m > kMaxSpecs) return PCX_OK;
     const int d = h->sd.d;
     const int np = h->n_pieces;
+    // every piece on the same lane-per-point form: 4 (k_bary_small) or 5 (k_bary_sq: equal trailing node counts)
+    const int form = bary_effective_variant(h->pieces[0]);
+    if (form != 4 && form != 5) return PCX_OK;
     for (int i = 0; i < np; ++i)
-        if (counts[i] && bary_effective_variant(h->pieces[i]) != 4) return PCX_OK;
+        if (counts[i] && bary_effective_variant(h->pieces[i]) != form) return PCX_OK;
     long blocks = 0;
     for (int i = 0; i < np; ++i) blocks += (counts[i] + 63) / 64;
     if (blocks == 0) { *done = true; return PCX_OK; }
@@ -1752,7 +1785,8 @@ static int spline_launch_fused(pcx_spline *h, const double *dp, const std::vecto
     const pcx_bary *p0 = h->pieces[0];
     const int *perm = (const int *)h->s_perm.ptr;
     const SplinePieceModel *dm = (const SplinePieceModel *)h->s_models.ptr;
-    switch (d) {
+    if (form == 5) rc = launch_sq_pieces(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream);
+    else switch (d) {
     case 1: rc = launch_small_pieces_d<0>(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream); break;
     case 2: rc = launch_small_pieces_d<1>(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream); break;
     case 3: rc = launch_small_pieces_d<2>(p0, dm, d_piece, d_first, d_end, m, blocks, dp, dout, perm, h->stream); break;

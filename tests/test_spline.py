@@ -254,3 +254,40 @@ def test_spline_one_launch_for_all_pieces_equals_launch_per_piece(monkeypatch):
                  sp.eval_batch(some, case["specs"][1]), sp.eval_batch(pts[:1], case["specs"][0])]
     for a, b in zip(fused, per_piece):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_spline_with_equal_trailing_node_counts_runs_on_the_sq_kernel(monkeypatch, oracle_mod):
+    """Pieces whose last two dimensions share a node count take k_bary_sq (round 3), in ONE launch for all pieces
+    (k_bary_sq_pieces) or one per piece (PCX_SPLINE_FUSED=0): bit-identical to each other, <= 1e-12 against the oracle;
+    single- and multi-spec, a batch that leaves pieces empty, device-resident points."""
+    from pychebyshev_amd.device import DeviceArray
+    dom = [[80.0, 120.0], [0.01, 0.25], [0.1, 0.4]]
+    knots = [[95.0, 100.0, 105.0], [0.1], []]
+    sp = ChebyshevSpline(F.call_payoff_3d, 3, dom, n_nodes=[6, 9, 9], knots=knots)
+    sp.build(verbose=False)
+    assert sp.num_pieces == 8
+    s = sp._dev()
+    piece = sp._pieces[0]._model()
+    info = _lib.i32(np.zeros(6))
+    piece.lib.pcx_bary_kernel_info(piece.handle, _lib.p_i32(info))
+    assert info[0] == 5
+    rng = np.random.default_rng(29)
+    pts = np.column_stack([rng.uniform(lo, hi, 120_001) for lo, hi in dom])
+    some = pts.copy()
+    some[:, 0] = np.where(some[:, 0] > 100.0, 99.0, some[:, 0])          # the S > 100 pieces stay empty
+    specs = [[0, 0, 0], [1, 0, 0], [0, 1, 1]]
+    fused = [sp.eval_batch(pts, specs[0]), sp.eval_multi_batch(pts, specs), sp.eval_batch(some, specs[1]),
+             sp.eval_batch(pts[:1], specs[0])]
+    assert np.array_equal(sp.eval_multi_batch(DeviceArray.from_host(pts), specs).to_host(), fused[1])
+    models = [oracle_mod.BaryModel(p.nodes, p.weights, p.diff_matrices, p.tensor_values) for p in sp._pieces]
+    sub = rng.choice(len(pts), 5000, replace=False)
+    for j, sp_ in enumerate(specs):
+        ref = oracle_mod.spline_eval_batch(models, sp.knots, sp._shape, pts[sub], sp_)
+        assert_parity(fused[1][sub, j], ref, 1e-12, f"sq spline {sp_}", float("inf"))
+    monkeypatch.setenv("PCX_SPLINE_FUSED", "0")
+    sp.to_device(0)                                                        # new handle, created under the override
+    per_piece = [sp.eval_batch(pts, specs[0]), sp.eval_multi_batch(pts, specs), sp.eval_batch(some, specs[1]),
+                 sp.eval_batch(pts[:1], specs[0])]
+    for a, b in zip(fused, per_piece):
+        assert np.array_equal(a, b)
