@@ -31,6 +31,9 @@ def bary_case(rng, stats):
     cap = 24 if d <= 2 else (16 if d <= 4 else (7 if d <= 6 else 3))
     while True:
         shape = tuple(int(rng.integers(1, cap + 1)) for _ in range(d))
+        if 2 <= d <= 4 and rng.random() < 0.4:                     # equal trailing node counts: k_bary_sq's shapes
+            nl = int(rng.choice([4, 5, 7, 8, 11, 13, 16, 17, 20, 21, 23, 24, 32] if d <= 3 else [4, 5, 6, 8, 9]))
+            shape = shape[:-2] + (nl, nl)
         if np.prod(shape) <= 300_000:
             break
     dom = []
@@ -60,7 +63,7 @@ def bary_case(rng, stats):
     scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(Td))), 1e-300)
     m = c._model()
     fails = []
-    for variant in (0, 1, 2, 3, 4):
+    for variant in (0, 1, 2, 3, 4, 5):
         if variant and m.lib.pcx_bary_set_kernel(m.handle, variant) != 0:
             continue
         got = c.vectorized_eval_batch(pts, spec)
