@@ -316,7 +316,6 @@ struct pcx_bary {
     bool small_preferred = false;    // auto picks it (few row tiles: the MFMA kernel would be all prologue)
     int sq_nl = 0;                   // k_bary_sq (last two dimensions of sq_nl nodes each, d <= 4): 0 = not available
     bool sq_preferred = false;       // auto picks it
-    bool in_spline = false;          // a piece of a pcx_spline
     int variant = 0;                 // 0 auto, 1 rows, 2 mfma 16x16x4, 3 mfma 4x4x4_4b, 4 lane-per-point (small tensors)
     std::mutex mu;
     std::map<std::vector<int>, DerivedTensor> cache;
@@ -1598,7 +1597,6 @@ extern "C" int pcx_spline_create(int device, int d, const int32_t *n_knots, cons
     if (nk_total > 0 && !knots_cat) { delete h; return fail(PCX_ERR_INVALID, "knots_cat is NULL"); }
     for (int i = 0; i < n_pieces; ++i) {
         if (!pieces[i] || pieces[i]->device != device || pieces[i]->dims.d != d) { delete h; return fail(PCX_ERR_INVALID, "piece %d is NULL, on another device or of another dimension", i); }
-        pieces[i]->in_spline = true;
         h->pieces.push_back(pieces[i]);
     }
     h->n_pieces = n_pieces;
