@@ -636,7 +636,9 @@ def run_rank(args) -> int:
                     source = f"cached PMC (not collected in this run): {r.get('source')}"
             except Exception:
                 traffic = None
-        return {"bound": "mfma", "kernel": wl.kernel, "achieved": achieved,
+        pipe = ("FP64 VALU (v_fma_f64, lane per point): the FP64 vector peak equals the FP64 matrix peak on MI355X and the two "
+                "share one pipe, so the same 78.6 TFLOP/s roofline binds") if "lpp" in wl.kernel else "FP64 MFMA (v_mfma_f64_16x16x4_f64)"
+        return {"bound": "mfma", "pipe": pipe, "kernel": wl.kernel, "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
                 "avg_launch_ms": avg_launch_s * 1e3,
