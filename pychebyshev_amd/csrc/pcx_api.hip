@@ -2613,43 +2613,52 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
     const bool piped = N >= 2 * kTTPipePoints;
     const int64_t chunk = piped ? kTTPipePoints : kChunkPoints;
     if (piped && !h->stream2) HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    int slot = 0;
-    int64_t prev_start = -1;
-    long prev_cnt = 0;
-    auto download = [&](int sl, int64_t start, long cnt) -> int {
-        const bool second = piped && sl == 1;
-        HIP_TRY(hipMemcpyAsync(out + start, (second ? h->s_out2 : h->s_out).ptr, (size_t)cnt * sizeof(double),
-                               hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
+    // the copies queued below read and write the CALLER's arrays: whatever happens, both streams are drained before
+    // this call returns (an early error return must not leave a download in flight behind it)
+    auto pipeline = [&]() -> int {
+        int slot = 0;
+        int64_t prev_start = -1;
+        long prev_cnt = 0;
+        auto download = [&](int sl, int64_t start, long cnt) -> int {
+            const bool second = piped && sl == 1;
+            HIP_TRY(hipMemcpyAsync(out + start, (second ? h->s_out2 : h->s_out).ptr, (size_t)cnt * sizeof(double),
+                                   hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
+            return PCX_OK;
+        };
+        for (int64_t start = 0; start < N; start += chunk, slot ^= 1) {
+            long cnt = (long)std::min<int64_t>(chunk, N - start);
+            const bool second = piped && slot == 1;
+            hipStream_t st = second ? h->stream2 : h->stream;
+            Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
+            int rc = sp.reserve((size_t)cnt * d * sizeof(double));
+            if (rc) return rc;
+            if ((rc = so.reserve((size_t)cnt * sizeof(double)))) return rc;
+            HIP_TRY(hipMemcpyAsync(sp.ptr, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
+            rc = tt_launch(h, (const double *)sp.ptr, cnt, (double *)so.ptr, st);
+            if (rc) return rc;
+            if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
+            if (!piped) {                           // single slot: drain before its buffers are reused
+                if ((rc = download(slot, start, cnt))) return rc;
+                HIP_TRY(hipStreamSynchronize(st));
+                prev_start = -1;
+                slot ^= 1;
+                continue;
+            }
+            prev_start = start;
+            prev_cnt = cnt;
+        }
+        if (prev_start >= 0) {
+            int rc = download(slot ^ 1, prev_start, prev_cnt);
+            if (rc) return rc;
+        }
         return PCX_OK;
     };
-    for (int64_t start = 0; start < N; start += chunk, slot ^= 1) {
-        long cnt = (long)std::min<int64_t>(chunk, N - start);
-        const bool second = piped && slot == 1;
-        hipStream_t st = second ? h->stream2 : h->stream;
-        Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
-        int rc = sp.reserve((size_t)cnt * d * sizeof(double));
-        if (rc) return rc;
-        if ((rc = so.reserve((size_t)cnt * sizeof(double)))) return rc;
-        HIP_TRY(hipMemcpyAsync(sp.ptr, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
-        rc = tt_launch(h, (const double *)sp.ptr, cnt, (double *)so.ptr, st);
-        if (rc) return rc;
-        if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
-        if (!piped) {                           // single slot: drain before its buffers are reused
-            if ((rc = download(slot, start, cnt))) return rc;
-            HIP_TRY(hipStreamSynchronize(st));
-            prev_start = -1;
-            slot ^= 1;
-            continue;
-        }
-        prev_start = start;
-        prev_cnt = cnt;
-    }
-    if (prev_start >= 0) {
-        int rc = download(slot ^ 1, prev_start, prev_cnt);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
+    const int rc_pipe = pipeline();
+    const hipError_t e1 = hipStreamSynchronize(h->stream);
+    const hipError_t e2 = h->stream2 ? hipStreamSynchronize(h->stream2) : hipSuccess;
+    if (rc_pipe) return rc_pipe;
+    HIP_TRY(e1);
+    HIP_TRY(e2);
     return PCX_OK;
 }
 
