@@ -287,6 +287,95 @@ k_tt_lpp3(Lpp3Plan plan, const double *__restrict__ img, const double *__restric
     if (p < N) out[p] = vl[0];
 }
 
+// V5: the product's shape with NP points per lane (each scalar operand feeds NP FMAs; per-dimension overhead per 64 NP points)
+template <int RL, int NJ, int NP>
+__device__ __forceinline__ void lpp5_body(pcx_lpp_cptr G, int rr, const double (&x)[NP], double *vl) {
+    double T[NP][NJ], v[NP][RL];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const double x2 = x[q] + x[q];
+        T[q][0] = 1.0;
+        asm volatile("" : "+v"(T[q][0]));
+        if constexpr (NJ > 1) T[q][1] = x[q];
+#pragma unroll
+        for (int j = 2; j < NJ; ++j) T[q][j] = __builtin_fma(x2, T[q][j - 1], -T[q][j - 2]);
+#pragma unroll
+        for (int a = 0; a < RL; ++a) v[q][a] = vl[(a * NP + q) * PCX_LPP_WG];
+    }
+    for (int b = 0; b < rr; ++b, G += RL * NJ) {
+        double M[NP][RL];
+#pragma unroll
+        for (int a = 0; a < RL; ++a) {
+            const double g = G[a * NJ];
+#pragma unroll
+            for (int q = 0; q < NP; ++q) M[q][a] = g * T[q][0];
+        }
+#pragma unroll
+        for (int j = 1; j < NJ; ++j)
+#pragma unroll
+            for (int a = 0; a < RL; ++a) {
+                const double g = G[a * NJ + j];
+#pragma unroll
+                for (int q = 0; q < NP; ++q) M[q][a] = __builtin_fma(T[q][j], g, M[q][a]);
+            }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            double s0 = v[q][0] * M[q][0];
+#pragma unroll
+            for (int a = 1; a < RL; ++a) s0 = __builtin_fma(v[q][a], M[q][a], s0);
+            vl[(b * NP + q) * PCX_LPP_WG] = s0;
+        }
+    }
+}
+
+template <int NJ, int NP, int MINB>
+__global__ void __launch_bounds__(PCX_LPP_WG, MINB)
+k_tt_lpp5(const TTLppDim *__restrict__ tab, int d, const double *__restrict__ img, const double *__restrict__ pts,
+          double *__restrict__ out, long N) {
+    extern __shared__ double lds_lpp[];
+    double *vl = lds_lpp + threadIdx.x;
+    typedef const TTLppDim __attribute__((address_space(4))) *tab_cptr;
+    const tab_cptr ct = (tab_cptr)(unsigned long long)tab;
+    const pcx_lpp_cptr cimg = (pcx_lpp_cptr)(unsigned long long)img;
+    long pc[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const long p = ((long)blockIdx.x * NP + q) * PCX_LPP_WG + threadIdx.x;      // coalesced output: point q of lane l
+        pc[q] = p < N ? p : N - 1;
+        vl[q * PCX_LPP_WG] = 1.0;
+    }
+    double xn[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) xn[q] = pts[pc[q] * d + ct[0].col];
+    for (int k = 0; k < d; ++k) {
+        double x[NP];
+#pragma unroll
+        for (int q = 0; q < NP; ++q) x[q] = __builtin_fma(xn[q] - ct[k].lo, ct[k].scale, -1.0);
+        if (k + 1 < d) {
+#pragma unroll
+            for (int q = 0; q < NP; ++q) xn[q] = pts[pc[q] * d + ct[k + 1].col];
+        }
+        const pcx_lpp_cptr G = cimg + ct[k].off;
+        const int rl = ct[k].rl, rr = ct[k].rr;
+        switch (rl) {
+        case 1: lpp5_body<1, NJ, NP>(G, rr, x, vl); break;
+        case 2: lpp5_body<2, NJ, NP>(G, rr, x, vl); break;
+        case 3: lpp5_body<3, NJ, NP>(G, rr, x, vl); break;
+        case 4: lpp5_body<4, NJ, NP>(G, rr, x, vl); break;
+        case 5: lpp5_body<5, NJ, NP>(G, rr, x, vl); break;
+        case 6: lpp5_body<6, NJ, NP>(G, rr, x, vl); break;
+        case 7: lpp5_body<7, NJ, NP>(G, rr, x, vl); break;
+        case 8: lpp5_body<8, NJ, NP>(G, rr, x, vl); break;
+        default: break;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+        const long p = ((long)blockIdx.x * NP + q) * PCX_LPP_WG + threadIdx.x;
+        if (p < N) out[p] = vl[q * PCX_LPP_WG];
+    }
+}
+
 int main(int argc, char **argv) {
     const long N = argc > 1 ? atol(argv[1]) : 10000000L;
     const int D = 5, n = 11;
@@ -461,6 +550,17 @@ int main(int argc, char **argv) {
         const long blocks = (N + PCX_LPP_WG - 1) / PCX_LPP_WG;
         time_it("V4 product k_tt_eval_lpp<8,11>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<8, 11>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
         time_it("V4 product k_tt_eval_lpp<16,11>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<16, 11>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
+#define RUN_LPP5(NP, MINB)                                                                                            \
+        {                                                                                                             \
+            const size_t l5 = (size_t)8 * NP * PCX_LPP_WG * 8;                                                        \
+            const long b5 = (N + (long)PCX_LPP_WG * NP - 1) / ((long)PCX_LPP_WG * NP);                                \
+            char name[96]; snprintf(name, sizeof name, "V5 product shape NP=%d MINB=%d", NP, MINB);                   \
+            time_it(name, [&] { hipLaunchKernelGGL((k_tt_lpp5<11, NP, MINB>), dim3((unsigned)b5), dim3(PCX_LPP_WG), l5, 0, d_tab, D, d_img, d_pts, d_out, N); }); \
+        }
+        RUN_LPP5(1, 8)
+        RUN_LPP5(2, 4)
+        RUN_LPP5(2, 3)
+        RUN_LPP5(3, 2)
         time_it("V4 product k_tt_eval_lpp<8,0>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<8, 0>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
         time_it("V4 product k_tt_eval_lpp<16,0>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<16, 0>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
     }
