@@ -46,54 +46,91 @@ __device__ __forceinline__ void tt_mfma_nodes(const double *__restrict__ fk, int
                                               const double (&s)[NT], pcx_d4 (&acc)[NT][RT]) {
     constexpr int F = RCX * RT;          // fragments per node
     constexpr bool PINGPONG = (F <= 8);
-    double tprev[NT], tcur[NT];
+    // B operands from the Chebyshev recurrence applied to the PRODUCTS z_j = v T_j (as in k_tt_eval_d4):
+    //     z_{j+1} = 2 s z_j - z_{j-1},   z_0 = v,  z_1 = s v
+    // one FMA per (chunk, column tile) and node -- no table of T_j, no multiply per MFMA (round 2: one multiply per
+    // MFMA plus the T recurrence, 20 vector instructions per 16 MFMAs; now 16).  The recurrence runs IN PLACE,
+    // alternating two names: za <- 2s zb - za = z_{j+2} after node j, zb <- 2s za - zb = z_{j+3} after node j+1 -- two
+    // nodes later every value sits in the register it started in, so the two-node loop body needs no register moves
+    // (round 2 rotated three names through two: hipcc closed the loop with ~17 v_mov_b64 per 32 MFMAs).
+    constexpr int RCV = RCX > 0 ? RCX : 1;
+    double za[NT][RCV], zb[NT][RCV], s2[NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { tprev[nt] = 1.0; tcur[nt] = s[nt]; }
+    for (int nt = 0; nt < NT; ++nt) {
+        s2[nt] = s[nt] + s[nt];
+#pragma unroll
+        for (int c = 0; c < RCX; ++c) { za[nt][c] = v[nt][c]; zb[nt][c] = v[nt][c] * s[nt]; }
+    }
 
     auto load = [&](double (&a)[F], int j) {
         const double *fj = fk + (size_t)j * F * 64;
 #pragma unroll
         for (int f = 0; f < F; ++f) a[f] = fj[f * 64];
     };
-    auto node = [&](const double (&a)[F], int j) {
-        double q[NT];                      // (tprev, tcur) = (T_j, T_{j+1}) on entry
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            q[nt] = tprev[nt];
-            const double tn = __builtin_fma(2.0 * s[nt], tcur[nt], -tprev[nt]);
-            tprev[nt] = tcur[nt];
-            tcur[nt] = tn;
-        }
-        (void)j;
+    // one node: the MFMAs on z_j (q), then q <- z_{j+2} in place (o: z_{j+1})
+    auto node = [&](const double (&a)[F], double (&q)[NT][RCV], const double (&o)[NT][RCV]) {
 #pragma unroll
         for (int c = 0; c < RCX; ++c) {
-            double bop[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) bop[nt] = v[nt][c] * q[nt];
 #pragma unroll
             for (int t = 0; t < RT; ++t)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c * RT + t], bop[nt], acc[nt][t], 0, 0, 0);
+                    acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c * RT + t], q[nt][c], acc[nt][t], 0, 0, 0);
         }
+#pragma unroll
+        for (int c = 0; c < RCX; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) q[nt][c] = __builtin_fma(s2[nt], o[nt][c], -q[nt][c]);
     };
 
     if (PINGPONG) {
+        // the fragments of node j+1 are requested BEFORE node j is multiplied and those of node j+2 before node j+1:
+        // fenced, because hipcc otherwise sinks each load next to its first use (one exposed L2 round trip per
+        // two nodes: s_waitcnt vmcnt right behind the load, profiles/r03_tt10d_*)
         double a0[F], a1[F];
         load(a0, 0);
-        for (int j = 0; j < n; j += 2) {
-            load(a1, (j + 1 < n) ? j + 1 : j);
-            node(a0, j);
-            if (j + 1 < n) {
-                load(a0, (j + 2 < n) ? j + 2 : j + 1);
-                node(a1, j + 1);
-            }
+        int j = 0;
+        // full pairs only: both loads of the body are used unconditionally (a load whose only use sits under an
+        // `if` is sunk into it by LLVM before scheduling, fences or not); an odd last node is peeled
+        for (; j + 1 < n; j += 2) {
+            load(a1, j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            node(a0, za, zb);
+            __builtin_amdgcn_sched_barrier(0);
+            load(a0, (j + 2 < n) ? j + 2 : j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            node(a1, zb, za);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        if (j < n) node(a0, za, zb);
     } else {
+        // many fragments per node (ranks > 32): one multiply per MFMA on v T_j, as in round 2 (the product recurrence
+        // keeps 2 RCX more doubles live and measured 2.5 % slower at rank 64)
+        double tprev[NT], tcur[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) { tprev[nt] = 1.0; tcur[nt] = s[nt]; }
         for (int j = 0; j < n; ++j) {
             double a[F];
             load(a, j);
-            node(a, j);
+            double q[NT];                      // (tprev, tcur) = (T_j, T_{j+1}) on entry
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                q[nt] = tprev[nt];
+                const double tn = __builtin_fma(2.0 * s[nt], tcur[nt], -tprev[nt]);
+                tprev[nt] = tcur[nt];
+                tcur[nt] = tn;
+            }
+#pragma unroll
+            for (int c = 0; c < RCX; ++c) {
+                double bop[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bop[nt] = v[nt][c] * q[nt];
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[nt][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[c * RT + t], bop[nt], acc[nt][t], 0, 0, 0);
+            }
         }
     }
 }
@@ -202,21 +239,28 @@ k_tt_eval_mfma(TTDims dims, TTRanks rk, const double *__restrict__ frag,
 #pragma unroll
             for (int c = 0; c < RC; ++c) w[nt][c] = 0.0;
         }
-        const double *gl = last_in_lds ? (const double *)gl_lds : glast;
-        for (int j = 0; j < n; ++j) {
-            double gv[RC];
+        // the table is read through a pointer of KNOWN address space (LDS copy or global): as one generic pointer the
+        // loop was flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) per node
+        auto last_dim = [&](auto gl) {
+            for (int j = 0; j < n; ++j) {
+                double gv[RC];
 #pragma unroll
-            for (int c = 0; c < RC; ++c) gv[c] = gl[(4 * c + g) * n + j];
+                for (int c = 0; c < RC; ++c) gv[c] = gl[(4 * c + g) * n + j];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const double q = tp[nt];                   // T_j; (tp, tc) = (T_j, T_{j+1})
+                for (int nt = 0; nt < NT; ++nt) {
+                    const double q = tp[nt];                   // T_j; (tp, tc) = (T_j, T_{j+1})
 #pragma unroll
-                for (int c = 0; c < RC; ++c) w[nt][c] = __builtin_fma(q, gv[c], w[nt][c]);
-                const double tn = __builtin_fma(2.0 * sc[nt], tc[nt], -tp[nt]);
-                tp[nt] = tc[nt];
-                tc[nt] = tn;
+                    for (int c = 0; c < RC; ++c) w[nt][c] = __builtin_fma(q, gv[c], w[nt][c]);
+                    const double tn = __builtin_fma(2.0 * sc[nt], tc[nt], -tp[nt]);
+                    tp[nt] = tc[nt];
+                    tc[nt] = tn;
+                }
             }
-        }
+        };
+        typedef const double __attribute__((address_space(3))) *lds_cptr;
+        typedef const double __attribute__((address_space(1))) *glb_cptr;
+        if (last_in_lds) last_dim((lds_cptr)gl_lds);
+        else last_dim((glb_cptr)glast);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             long p = base + 16 * nt + c16;
