@@ -6,7 +6,8 @@
 // GEMM form per dimension, points on the MFMA N axis:
 //     v'[b, p] = sum_{(j,a)} G_k[a, j, b] * ( v[a, p] * T_j(s_k(p)) )
 //   A operand  = core fragment, lane l holds G_k[a = 4c + (l>>4)][j][b = 16t + (l&15)]
-//   B operand  = v[a = 4c + (l>>4), p = l&15] * q_j(p)              (one VALU multiply)
+//   B operand  = z_j = v[a = 4c + (l>>4), p = l&15] * T_j(p)        (round 3: from the recurrence on the products,
+//                                                                    one FMA; ranks > 16: one VALU multiply)
 //   D (16x16)  = lane l, reg i holds row b = 16t + (l>>4) + 4i, column p = l & 15
 // With the k index ordered (j, a) and ranks padded to multiples of 4, the row a a lane
 // needs as B operand for chunk c is exactly the row it already holds in D register

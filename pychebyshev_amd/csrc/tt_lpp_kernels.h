@@ -19,7 +19,8 @@
 // dimension by a switch, so ranks and node counts are exact -- nothing is padded.
 // image: img[off_k + (b * rl + a) * n + j] = G_k[a][j][b].
 // Measured on config 3 (5-D, ranks [1,8,8,8,6,1], n = 11; tools/tt_lpp_lab.hip,
-// profiles/r03_tt_lpp_lab.txt): 2,430 vector instructions per 64 points at 4.2 cycles each.
+// profiles/r03_tt_lpp_lab.txt): 2,469 vector instructions per 64 points at 4.2 cycles each, 0.70 - 0.78 of the FP64
+// peak depending on the clock the box settles at (round 2, k_tt_eval_d4: 0.555).
 #pragma once
 
 #include "pcx_common.h"
