@@ -2179,7 +2179,7 @@ struct pcx_tt {
     long d4_resident = 0;
     double *d_img4 = nullptr;
     // lane-per-point VALU form (tt_lpp_kernels.h; ranks <= 16, n <= 16): exact image [b][a][j] + per-dim table
-    int lppCap = 0;       // 0 = not available, else the instantiation's rank cap: 8 or 16
+    int lppCap = 0;       // 0 = not available, else the instantiation's rank cap: 8, 12 or 16
     int lpp_nodes = 0;    // the node count every dimension shares (instantiations with one switch level), 0 = they differ
     bool lpp_preferred = false;  // auto takes it (ranks <= 15: measured ahead of every MFMA form, profiles/r03_tt_rate_probe.txt)
     double *d_lpp_img = nullptr;
@@ -2435,7 +2435,7 @@ extern "C" int pcx_tt_create(int device, int d, const int32_t *n_nodes, const in
             hipMalloc((void **)&h->d_lpp_tab, tab.size() * sizeof(TTLppDim)) == hipSuccess &&
             hipMemcpy(h->d_lpp_img, img.data(), img.size() * sizeof(double), hipMemcpyHostToDevice) == hipSuccess &&
             hipMemcpy(h->d_lpp_tab, tab.data(), tab.size() * sizeof(TTLppDim), hipMemcpyHostToDevice) == hipSuccess) {
-            h->lppCap = h->rmax <= 8 ? 8 : 16;
+            h->lppCap = h->rmax <= 8 ? 8 : (h->rmax <= 12 ? 12 : 16);
             h->lpp_nodes = n_nodes[0];
             for (int k = 1; k < d; ++k)
                 if (n_nodes[k] != n_nodes[0]) h->lpp_nodes = 0;
@@ -2544,7 +2544,7 @@ static int tt_launch(pcx_tt *h, const double *d_pts, long N, double *d_out, hipS
         case 13: PCX_LPP_GO(RCAP, 13); break; case 14: PCX_LPP_GO(RCAP, 14); break; case 15: PCX_LPP_GO(RCAP, 15); break; \
         case 16: PCX_LPP_GO(RCAP, 16); break; default: PCX_LPP_GO(RCAP, 0); break;                                   \
         }
-        if (h->lppCap == 8) { PCX_LPP_GO_N(8) } else { PCX_LPP_GO_N(16) }
+        if (h->lppCap == 8) { PCX_LPP_GO_N(8) } else if (h->lppCap == 12) { PCX_LPP_GO_N(12) } else { PCX_LPP_GO_N(16) }
 #undef PCX_LPP_GO_N
 #undef PCX_LPP_GO
         HIP_TRY(hipGetLastError());

@@ -40,6 +40,9 @@ struct TTLppDim {
 #define PCX_LPP_MAX_RANK 16
 #define PCX_LPP_MAX_NODES 16
 #define PCX_LPP_WG 64
+#ifndef PCX_LPP_MINB12
+#define PCX_LPP_MINB12 6      // ranks 9..12 at <= 80 VGPRs: at 8 (<= 64 VGPRs) the rank-12 body spills (10-D rank 12: 0.55 against 0.65)
+#endif
 
 template <int RL, int NJ>
 __device__ __forceinline__ void tt_lpp_body(pcx_lpp_cptr G, int rr, double x, double *vl) {
@@ -83,9 +86,10 @@ __device__ __forceinline__ void tt_lpp_body(pcx_lpp_cptr G, int rr, double x, do
     case 3: tt_lpp_body<3, NJ>(G, rr, x, vl); break; case 4: tt_lpp_body<4, NJ>(G, rr, x, vl); break;     \
     case 5: tt_lpp_body<5, NJ>(G, rr, x, vl); break; case 6: tt_lpp_body<6, NJ>(G, rr, x, vl); break;     \
     case 7: tt_lpp_body<7, NJ>(G, rr, x, vl); break; case 8: tt_lpp_body<8, NJ>(G, rr, x, vl); break;
-#define PCX_LPP_RANK_CASES_16(NJ)                                                                         \
+#define PCX_LPP_RANK_CASES_12(NJ)                                                                         \
     case 9: tt_lpp_body<9, NJ>(G, rr, x, vl); break; case 10: tt_lpp_body<10, NJ>(G, rr, x, vl); break;   \
-    case 11: tt_lpp_body<11, NJ>(G, rr, x, vl); break; case 12: tt_lpp_body<12, NJ>(G, rr, x, vl); break; \
+    case 11: tt_lpp_body<11, NJ>(G, rr, x, vl); break; case 12: tt_lpp_body<12, NJ>(G, rr, x, vl); break;
+#define PCX_LPP_RANK_CASES_16(NJ)                                                                         \
     case 13: tt_lpp_body<13, NJ>(G, rr, x, vl); break; case 14: tt_lpp_body<14, NJ>(G, rr, x, vl); break; \
     case 15: tt_lpp_body<15, NJ>(G, rr, x, vl); break; case 16: tt_lpp_body<16, NJ>(G, rr, x, vl); break;
 
@@ -94,21 +98,24 @@ __device__ __forceinline__ void tt_lpp_dim(int rl, pcx_lpp_cptr G, int rr, doubl
     switch (rl) {
         PCX_LPP_RANK_CASES_8(NJ)
         default:
-            if constexpr (RCAP > 8) {
-                switch (rl) { PCX_LPP_RANK_CASES_16(NJ) default: break; }
+            if constexpr (RCAP > 12) {
+                switch (rl) { PCX_LPP_RANK_CASES_12(NJ) PCX_LPP_RANK_CASES_16(NJ) default: break; }
+            } else if constexpr (RCAP > 8) {
+                switch (rl) { PCX_LPP_RANK_CASES_12(NJ) default: break; }
             }
             break;
     }
 }
 
 // One wave per workgroup, one point per lane; dynamic LDS = max rank * 64 * 8 bytes (the lane-private
-// columns of v').  RCAP = 8 / 16: the left ranks the instantiation covers (its register budget follows
-// the largest body).  NJ = the node count when every dimension has the same one (the usual model: the
+// columns of v').  RCAP = 8 / 12 / 16: the left ranks the instantiation covers (its register budget follows
+// the largest body; the reference's max_rank = 15 Black-Scholes model, ranks [1,11,11,11,7,1], runs on RCAP = 12:
+// 0.72 of the FP64 peak against 0.68 on RCAP = 16).  NJ = the node count when every dimension has the same one (the usual model: the
 // kernel then holds only the <= RCAP bodies of that node count, and hipcc allocates registers far better
 // than across the 256 bodies of the two-level switch), 0 = node counts differ: dispatch on both.
 // The coordinate of dimension k + 1 is fetched while dimension k is contracted.
 template <int RCAP, int NJ>
-__global__ void __launch_bounds__(PCX_LPP_WG, RCAP <= 8 ? 8 : 4)
+__global__ void __launch_bounds__(PCX_LPP_WG, RCAP <= 8 ? 8 : (RCAP <= 12 ? PCX_LPP_MINB12 : 4))
 k_tt_eval_lpp(const TTLppDim *__restrict__ tab, int d, const double *__restrict__ img,
               const double *__restrict__ pts, double *__restrict__ out, long N) {
     extern __shared__ double lds_lpp[];

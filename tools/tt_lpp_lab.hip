@@ -564,5 +564,39 @@ int main(int argc, char **argv) {
         time_it("V4 product k_tt_eval_lpp<8,0>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<8, 0>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
         time_it("V4 product k_tt_eval_lpp<16,0>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<16, 0>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
     }
+    // ---- V6: ranks 9..15 (the reference's max_rank = 15 Black-Scholes model has ranks [1,11,11,11,7,1]) ----------
+    {
+        const int ranks2[6] = {1, 11, 11, 11, 7, 1};
+        std::vector<double> cores2; std::vector<long> off2(D);
+        RefModel rm2 = rm;
+        for (int k = 0; k < D; ++k) {
+            rm2.r[k] = ranks2[k]; rm2.off[k] = (long)cores2.size(); off2[k] = rm2.off[k];
+            for (int i = 0; i < ranks2[k] * n * ranks2[k + 1]; ++i) cores2.push_back(nd(rng) / std::sqrt((double)ranks2[k] * n));
+        }
+        rm2.r[D] = 1;
+        double *d_cores2; CK(hipMalloc(&d_cores2, cores2.size() * 8)); CK(hipMemcpy(d_cores2, cores2.data(), cores2.size() * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_ref, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, 0, rm2, d_cores2, d_pts, d_ref, N);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(ref.data(), d_ref, N * 8, hipMemcpyDeviceToHost));
+        scale = 0; for (double v : ref) scale = std::max(scale, std::fabs(v));
+        std::vector<TTLppDim> tab(D);
+        std::vector<double> img;
+        double fma = 0;
+        for (int k = 0; k < D; ++k) {
+            tab[k] = TTLppDim{(int)img.size(), ranks2[k], ranks2[k + 1], n, k, 0, rm.lo[k], 2.0 / (rm.hi[k] - rm.lo[k])};
+            const double *G = cores2.data() + off2[k];
+            const int rl = ranks2[k], rr = ranks2[k + 1];
+            fma += (double)(n + 1) * rl * rr;
+            for (int b = 0; b < rr; ++b) for (int a = 0; a < rl; ++a) for (int j2 = 0; j2 < n; ++j2) img.push_back(G[((long)a * n + j2) * rr + b]);
+        }
+        for (int i = 0; i < 64; ++i) img.push_back(0.0);
+        double *d_img; CK(hipMalloc(&d_img, img.size() * 8)); CK(hipMemcpy(d_img, img.data(), img.size() * 8, hipMemcpyHostToDevice));
+        TTLppDim *d_tab; CK(hipMalloc(&d_tab, sizeof(TTLppDim) * D)); CK(hipMemcpy(d_tab, tab.data(), sizeof(TTLppDim) * D, hipMemcpyHostToDevice));
+        const size_t ldsb = (size_t)12 * PCX_LPP_WG * 8;
+        const long blocks = (N + PCX_LPP_WG - 1) / PCX_LPP_WG;
+        printf("ranks [1,11,11,11,7,1]: %.0f FMA per point; the fractions printed below assume 2,280 -- multiply by %.3f\n", fma, fma / 2280.0);
+        time_it("V6 r15 k_tt_eval_lpp<16,11>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<16, 11>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
+        time_it("V6 r15 k_tt_eval_lpp<12,11>", [&] { hipLaunchKernelGGL((k_tt_eval_lpp<12, 11>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), ldsb, 0, d_tab, D, d_img, d_pts, d_out, N); });
+    }
     return 0;
 }
