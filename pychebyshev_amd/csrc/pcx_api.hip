@@ -246,7 +246,7 @@ static const int64_t kPipeChunkPoints = 1 << 18;
 // device-mapped buffer the kernel reads directly over PCIe, and the results land in a second
 // pinned buffer (coherent host memory: visible after the stream sync).  Two API calls fewer
 // per query; this is the single-query latency path.
-static const size_t kPinnedBytes = 64 * 1024;
+static const size_t kPinnedBytes = 512 * 1024;
 struct Pinned {
     void *in = nullptr, *out = nullptr;
     bool tried = false;
