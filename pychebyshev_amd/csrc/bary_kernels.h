@@ -728,10 +728,9 @@ k_bary_rows(BaryDims dims, int LPP, const double *__restrict__ nodes,
 // for a 12 x 12 tensor the weights, not the 156 FMAs of the contraction, are most of the work.
 // 2^e (a power of two near 2 / width, so that the products of up to 64 factors stay far from
 // over/underflow) is applied exactly: snodes = nodes 2^e is precomputed and t_i = fma(x, 2^e,
-// -snodes_i) is the correctly rounded (x - x_i) 2^e.  A coordinate exactly on node j gives the
-// one-hot row exactly (every other product contains the factor 0; b_j = c_j / c_j = 1); within
-// 1e-14 of a node, where the reference switches to the node's value, this evaluates the
-// interpolant at x itself -- the two differ by O(1e-14), far inside the 1e-12 bar.
+// -snodes_i) is the correctly rounded (x - x_i) 2^e.  Within 1e-14 of a node the
+// reference switches to the node's slice (barycentric.py:1039-1043) and so does this: a divergent fix-up
+// behind one v_min per node, see bary_weights_reg (round 3; round 2 evaluated the interpolant at x there).
 // Model data the evaluation kernels only read (tensor, scaled nodes, weights) goes through a
 // CONSTANT-address-space pointer: with a wave-uniform address that is what lets hipcc use scalar loads
 // (s_load into SGPRs) whatever it can or cannot prove about aliasing with `out` -- a plain `const double *`
@@ -745,13 +744,14 @@ template <int NLP, bool EXACT>
 __device__ __forceinline__ void bary_weights_reg(double x, double scale, pcx_cptr snodes, pcx_cptr wts, int n,
                                                  double (&b)[NLP]) {
     double t[NLP];
-    double run = 1.0;
+    double run = 1.0, amin = 1.0e300;
 #pragma unroll
     for (int j = 0; j < NLP; ++j) {                 // b_j <- w_j * prefix_j
         b[j] = 0.0;
         t[j] = 1.0;
         if (EXACT || j < n) {
             t[j] = __builtin_fma(x, scale, -snodes[j]);
+            amin = __builtin_fmin(amin, __builtin_fabs(t[j]));
             b[j] = wts[j] * run;
             run *= t[j];
         }
@@ -769,15 +769,31 @@ __device__ __forceinline__ void bary_weights_reg(double x, double scale, pcx_cpt
     const double r = 1.0 / su;
 #pragma unroll
     for (int j = 0; j < NLP; ++j) b[j] *= r;
+    // The reference's node rule, literally (barycentric.py:1039-1043): within 1e-14 of a node -- |x - x_j| < 1e-14 is
+    // |t_j| < 1e-14 2^e exactly, t_j being the correctly rounded (x - x_j) 2^e -- the FIRST such node's slice is taken.
+    // One v_min per node on the common path; the lanes it concerns (grid points, mostly) rewrite their row as one-hot,
+    // which also makes the weight of an exact node exactly 1.0 (c (1 / c) is not always 1).  Round 2 evaluated the
+    // interpolant at x there: O(1e-14 |f'|) away, which is no longer inside 1e-12 for 30 noisy nodes.
+    if (amin < 1e-14 * scale) {
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < NLP; ++j) {
+            const bool hit = !found && (EXACT || j < n) && __builtin_fabs(t[j]) < 1e-14 * scale;
+            b[j] = hit ? 1.0 : 0.0;
+            found = found || hit;
+        }
+    }
 }
 
 // The same through a lane's column of an LDS table (runtime node count): dst[j * stride].
 __device__ __forceinline__ void bary_weights_prod(double x, double scale, pcx_cptr snodes, pcx_cptr wts, int n,
                                                   double *dst, int stride) {
-    double run = 1.0;
+    double run = 1.0, amin = 1.0e300;
     for (int j = 0; j < n; ++j) {
         dst[j * stride] = wts[j] * run;
-        run *= __builtin_fma(x, scale, -snodes[j]);
+        const double t = __builtin_fma(x, scale, -snodes[j]);
+        amin = __builtin_fmin(amin, __builtin_fabs(t));
+        run *= t;
     }
     run = 1.0;
     double su = 0.0;
@@ -789,6 +805,14 @@ __device__ __forceinline__ void bary_weights_prod(double x, double scale, pcx_cp
     }
     const double r = 1.0 / su;
     for (int j = 0; j < n; ++j) dst[j * stride] *= r;
+    if (amin < 1e-14 * scale) {                     // the reference's node rule: see bary_weights_reg
+        bool found = false;
+        for (int j = 0; j < n; ++j) {
+            const bool hit = !found && __builtin_fabs(__builtin_fma(x, scale, -snodes[j])) < 1e-14 * scale;
+            dst[j * stride] = hit ? 1.0 : 0.0;
+            found = found || hit;
+        }
+    }
 }
 
 template <int LEVEL, int DOUT, int NLP>

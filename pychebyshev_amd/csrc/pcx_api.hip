@@ -519,7 +519,7 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
                 if (v >= nl) { h->small_nlp = v; break; }
             h->small_preferred = total <= kSmallTensorElems && nl <= 48;
             // mid-size tensors with equal trailing node counts: both trailing weight vectors in registers (k_bary_sq)
-            if (d >= 2 && n_nodes[d - 2] == nl && ((nl >= 4 && nl <= 24) || nl == 32) &&
+            if (d >= 2 && n_nodes[d - 2] == nl && ((nl >= 4 && nl <= 24) || nl == 26 || nl == 28 || nl == 30 || nl == 32) &&
                 (outer_rows - nl) * 64 * (long)sizeof(double) <= 48 * 1024) {
                 h->sq_nl = nl;
                 static const bool sq_auto = [] { const char *e = getenv("PCX_BARY_SQ"); return !(e && e[0] == '0'); }();
@@ -528,7 +528,9 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
                 // (17^3 +48 %, 20^3 +11 %, 24^3 +15 %); from 10^4 up the MFMA kernel (K = n^2 >= 100) is ahead
                 // 21 and 23 nodes: hipcc runs out of scalar registers on the odd row length (SGPR spills in the block,
                 // 0.37 / 0.36 of the peak against 0.39 / 0.44 on the MFMA kernel): available, not preferred
-                h->sq_preferred = sq_auto && (d <= 3 || total <= kSmallTensorElems) && nl != 21 && nl != 23;
+                // 26 / 28 / 30 nodes: ahead in 2-D (26^2 0.40 against 0.21), behind the MFMA kernel in 3-D (30^3 0.32 against 0.42)
+                h->sq_preferred = sq_auto && (d <= 3 || total <= kSmallTensorElems) && nl != 21 && nl != 23 &&
+                                  !(d >= 3 && nl > 24 && nl != 32);
             }
             // 2^e ~ 2 / (node span): exact to apply, keeps the prefix / suffix products of the weights in range
             std::vector<double> sn((size_t)sum_n);
@@ -1029,7 +1031,7 @@ static int launch_sq(pcx_bary *h, const DerivedTensor &dt, const double *const *
 #define CASE_NL(v) case v: return launch_sq_t<v>(h, dt, T_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
     CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(7) CASE_NL(8) CASE_NL(9) CASE_NL(10) CASE_NL(11) CASE_NL(12) CASE_NL(13)
     CASE_NL(14) CASE_NL(15) CASE_NL(16) CASE_NL(17) CASE_NL(18) CASE_NL(19) CASE_NL(20) CASE_NL(21) CASE_NL(22)
-    CASE_NL(23) CASE_NL(24) CASE_NL(32)
+    CASE_NL(23) CASE_NL(24) CASE_NL(26) CASE_NL(28) CASE_NL(30) CASE_NL(32)
 #undef CASE_NL
     }
     return fail(PCX_ERR_UNSUPPORTED, "square-trailing lane-per-point kernel does not cover this shape");
@@ -1709,7 +1711,7 @@ static int launch_sq_pieces(const pcx_bary *p0, const SplinePieceModel *models, 
 #define CASE_NL(v) case v: return launch_sq_pieces_t<v>(p0, models, blk_piece, blk_first, piece_end, m, blocks, dp, dout, perm, st);
     CASE_NL(4) CASE_NL(5) CASE_NL(6) CASE_NL(7) CASE_NL(8) CASE_NL(9) CASE_NL(10) CASE_NL(11) CASE_NL(12) CASE_NL(13)
     CASE_NL(14) CASE_NL(15) CASE_NL(16) CASE_NL(17) CASE_NL(18) CASE_NL(19) CASE_NL(20) CASE_NL(21) CASE_NL(22)
-    CASE_NL(23) CASE_NL(24) CASE_NL(32)
+    CASE_NL(23) CASE_NL(24) CASE_NL(26) CASE_NL(28) CASE_NL(30) CASE_NL(32)
 #undef CASE_NL
     }
     return fail(PCX_ERR_UNSUPPORTED, "square-trailing lane-per-point kernel does not cover this piece shape");
