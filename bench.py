@@ -91,27 +91,6 @@ def bs_5d(x, _=None):
     return S * math.exp(-BS_Q * T) * ncdf(d1) - K * math.exp(-r * T) * ncdf(d1 - sq)
 
 
-def count_gemms(specs, span=1):
-    """GEMMs one multi-spec step executes: specs with equal orders along dimensions 1.. and dim-0 orders within
-    [base, base + span] share one (the library's grouping rule, pcx_bary_set_group_span)."""
-    if span <= 0:
-        return len(specs)
-    by_key = {}
-    for s in specs:
-        by_key.setdefault(tuple(s[1:]), []).append(s[0])
-    total = 0
-    for orders in by_key.values():
-        orders = sorted(orders)
-        i = 0
-        while i < len(orders):
-            e = i
-            while e < len(orders) and orders[e] <= orders[i] + span:
-                e += 1
-            total += 1
-            i = e
-    return total
-
-
 def uniform_points(domain, n, seed):
     """One rng.uniform(lo, hi, n) per dimension, stacked column-wise (the reference's recipe)."""
     rng = np.random.default_rng(seed)
@@ -171,8 +150,8 @@ class Bary5D(Workload):
         self.m = self.model._model()
         self.spec_arrays = [lib_mod.i32(s) for s in self.specs]
         self.spec_block = lib_mod.i32(np.asarray(self.specs).reshape(-1))
-        # GEMMs a step executes: specs that differ by one order along dimension 0 share one (span 1: price + delta)
-        self.gemms_per_step = count_gemms(self.specs, 1) if n_points >= 65536 else len(self.specs)
+        # GEMMs a step executes: pairs of specs one order apart along one dimension share one (the library's count)
+        self.gemms_per_step = self.count_gemms()
 
     def points(self, rank):
         return uniform_points(BS5_DOMAIN, self.points_per_gpu, 99 + rank)
@@ -185,7 +164,7 @@ class Bary5D(Workload):
     def launch(self, d_pts, n, d_out, stream, which=None):
         """One spec (`which`, or a single-spec workload): one launch into out[which*n : (which+1)*n].  All specs of
         the Greeks workload: ONE multi-spec call into out (n x m, row-major) -- the library shares a GEMM between
-        specs that differ by one order along dimension 0 (price and delta; pcx_bary_set_group_span)."""
+        pairs of specs one order apart along one dimension (delta / gamma, price / vega; pcx_bary_set_group_span)."""
         if which is None and len(self.spec_arrays) > 1:
             self._lib.check(self.m.lib.pcx_bary_eval_multi_batch_dev(self.m.handle, d_pts, n, self._lib.p_i32(self.spec_block),
                                                                      len(self.spec_arrays), d_out, stream), self.m.lib)
@@ -199,6 +178,15 @@ class Bary5D(Workload):
 
     def set_group_span(self, span):
         self._lib.check(self.m.lib.pcx_bary_set_group_span(self.m.handle, span), self.m.lib)
+        self.gemms_per_step = self.count_gemms()
+
+    def count_gemms(self):
+        if len(self.specs) == 1:
+            return 1
+        out = self._lib.i32([0])
+        self._lib.check(self.m.lib.pcx_bary_count_gemms(self.m.handle, self._lib.p_i32(self.spec_block), len(self.specs),
+                                                        self.points_per_gpu, self._lib.p_i32(out)), self.m.lib)
+        return int(out[0])
 
     def host_eval(self, pts):
         """The host-pointer entry point (what ChebyshevApproximation.vectorized_eval_batch /
@@ -821,22 +809,24 @@ def run_rank(args) -> int:
                "unit": "point-evals/s", "ms_per_step": rec["elapsed"] / c_steps * 1e3, "steps": c_steps, "warmup": c_warm,
                "roofline": roofline_of(cwl, rec)}
         if name == "greeks5d":
-            out["roofline"]["flop_basis"] = ("EXECUTED GEMMs: 5 per step for 6 specs (price and delta share one slab-packed "
-                                             "GEMM, +4.8 % row tiles); avg_launch_ms = step / 5; `value` counts all 6 specs")
-            out["config"] = {"group_span": 1, "gemms_per_step": 5,
+            g = cwl.gemms_per_step
+            out["roofline"]["flop_basis"] = (f"EXECUTED GEMMs: {g} per step for {len(cwl.specs)} specs (delta / gamma share the delta "
+                                             "tensor's slab-packed GEMM, price / vega one along the volatility axis; +4.8 % row "
+                                             f"tiles each); avg_launch_ms = step / {g}; `value` counts all {len(cwl.specs)} specs")
+            out["config"] = {"group_span": 1, "gemms_per_step": g,
                              "parity": "every spec within 1e-12 (normwise) of the reference's batch results"}
-            # the same step with gamma folded into the price/delta GEMM (span 2) and with no sharing (span 0)
-            assert cwl.gemms_per_step == 5
-            for span, gemms, key, note in ((2, 4, "span2", "price + delta + gamma share one GEMM: gamma 4.4e-12 from the "
-                                                           "reference's batch path (outside the 1e-12 bar; opt-in)"),
-                                           (0, 6, "span0", "no sharing: one GEMM per spec (round 2's path)")):
+            # the same step with no sharing (span 0), and with dim-0 orders up to two apart sharing (span 2) when that
+            # saves a GEMM
+            for span, key, note in ((0, "span0", "no sharing: one GEMM per spec (round 2's path)"),
+                                    (2, "span2", "price + delta + gamma share one GEMM: gamma 4.4e-12 from the reference's "
+                                                 "batch path (outside the 1e-12 bar; opt-in)")):
                 cwl.set_group_span(span)
-                cwl.gemms_per_step = gemms
+                if span == 2 and cwl.gemms_per_step >= g:
+                    continue
                 r2 = measure(cwl, args.steps, args.warmup, headline_mode)
                 out[key] = {"value": rate(cwl, r2, args.steps), "ms_per_step": r2["elapsed"] / args.steps * 1e3,
-                            "gemms_per_step": gemms, "note": note}
+                            "gemms_per_step": cwl.gemms_per_step, "note": note}
             cwl.set_group_span(1)
-            cwl.gemms_per_step = 5
             if rank != 0:
                 return None
         if cwl.build_info:

@@ -154,13 +154,18 @@ int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const do
  * PCX_ERR_UNSUPPORTED when the shape is not covered.  info_out receives
  * {variant used by auto, row tiles, k-steps, lds bytes, points per workgroup, split}.  */
 int pcx_bary_set_kernel(pcx_bary *h, int variant);
-/* Multi-spec batches (pcx_bary_eval_multi_batch[_dev], N >= 65,536 on the MFMA kernel): specs that differ only in
- * their derivative order along dimension 0 by at most `span` share ONE contraction of dimensions 1 .. d-1 and are
- * finished with D_0 on the per-node partial sums -- the order of operations of the reference's
- * vectorized_eval_multi (barycentric.py:1098-1110).  span = 1 (default; PCX_BARY_G0_SPAN overrides it at load):
- * price and delta share a GEMM, within 2e-13 of the reference's batch results on 5-D Black-Scholes; span = 2 also
- * folds gamma in (one GEMM less, gamma then 4e-12 from the reference's batch path: each D_0 applied after the
- * contraction amplifies the rounding of the partial sums); span = 0: every spec gets its own GEMM.            */
+/* Multi-spec batches (pcx_bary_eval_multi_batch[_dev], N >= 65,536 on the MFMA kernel): a spec and the spec ONE order
+ * below it along any one dimension q (n_q <= 16) share ONE contraction of the other dimensions and are finished with
+ * D_q on the per-node partial sums -- the order of operations of the reference's vectorized_eval_multi
+ * (barycentric.py:1098-1110).  Pairs are found from the highest total order down: of price + 5 Greeks, delta / gamma
+ * share the delta tensor's GEMM and price / vega one along the volatility axis (4 GEMMs for 6 specs), every member
+ * within 2e-13 of the reference's batch results on 5-D Black-Scholes.  q > 0 runs on a copy of the model with q in
+ * front, built on first use (tensors up to 2^24 elements; launches on the handle's own streams only).
+ * span = 1 is that default (PCX_BARY_G0_SPAN overrides it at load); span = 2 first lets specs up to two dim-0 orders
+ * apart share (price / delta / gamma in one GEMM: gamma then 4e-12 from the reference's batch path, as each D_0
+ * applied after the contraction amplifies the rounding of the partial sums); span = 0: every spec its own GEMM.
+ * pcx_bary_count_gemms: the number of GEMM launches a call with these specs and N would execute.                 */
+int pcx_bary_count_gemms(pcx_bary *h, const int32_t *derivs, int m, int64_t N, int32_t *gemms_out);
 int pcx_bary_set_group_span(pcx_bary *h, int span);
 int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
 int pcx_bary_stream(pcx_bary *h, void **stream);

@@ -307,6 +307,11 @@ struct pcx_bary {
     int g0_nf = 2;                   // live row-code fields (head dimensions 1 .. split-1, at least two)
     unsigned *d_rowcode_g0 = nullptr;
     int g0_span = 1;                 // dim-0 orders above its base tensor's a slab GEMM serves (pcx_bary_set_group_span)
+    // dim-q groups (q > 0): the same model with dimension q moved to the front, built on first use (bary_rot); a pair of
+    // specs one order apart along q shares ITS dim-0 slab GEMM, on the batch with its columns in that order
+    pcx_bary *rot[PCX_MAX_DIMS] = {};
+    char rot_state[PCX_MAX_DIMS] = {};   // 0 untried, 1 ready, 2 not available
+    Scratch s_rot, s_rot2;           // the batch in a sub-model's column order (per staging slot)
     int lpp = 64;                    // lanes per point in the rows kernel
     bool mfma4_ok = false;           // 4x4x4_4b form available (LDS budget)
     int small_nlp = 0;               // lane-per-point kernel for small tensors: padded last-dim width, 0 = not available
@@ -404,6 +409,8 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
     (void)hipFree(h->d_rowcode_hi); (void)hipFree(h->d_kcode_hi);
     (void)hipFree(h->d_rowcode_g0);
+    for (pcx_bary *&r : h->rot) { if (r) pcx_bary_destroy(r); r = nullptr; }
+    h->s_rot.release(); h->s_rot2.release();
     h->s_pts.release(); h->s_out.release();
     h->s_pts2.release(); h->s_out2.release();
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
@@ -1140,23 +1147,81 @@ static int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const doub
     return PCX_OK;
 }
 
-// Multi-spec launch with dim-0 groups: specs (rows of `derivs`, m x d) that differ only in their order along
-// dimension 0 by at most g_g0_span -- price / delta; vega / vanna -- share one slab-packed GEMM over the tensor of the
-// lower order (the reference's own order in vectorized_eval_multi, barycentric.py:1098-1110: contract the later
-// dimensions, then apply D_0); every other spec keeps its own GEMM, launched in runs of consecutive columns.
-// Large batches on the MFMA kernel only; results of grouped specs differ from the per-spec path by rounding
-// (<= 2e-13 of the scale on 5-D Black-Scholes), as the reference's multi and batch paths do.  Caller holds h->mu.
-static int bary_launch_specs(pcx_bary *h, const int32_t *derivs, DerivedTensor *const *dts, int m,
-                             const double *const *frag_tab, const double *d_pts, long N, double *d_out, long ostride,
-                             long ooff, hipStream_t st, Scratch *split_scratch) {
+// The model with dimension q moved to the front (the other dimensions keep their order), or NULL when that shape has
+// no slab plan.  Built on first use from the device copies of the grid arrays and the value tensor: a transposed copy of a
+// tensor of at most 2^24 elements, once per handle and dimension.  Caller holds h->mu.
+static const long kRotMaxElems = 1L << 24;
+static pcx_bary *bary_rot(pcx_bary *h, int q) {
+    if (h->rot_state[q]) return h->rot[q];
+    h->rot_state[q] = 2;
     const int d = h->dims.d;
-    // a sub-group = the specs one slab GEMM serves: equal orders along dimensions 1 .. d-1 and dim-0 orders in
-    // [base, base + g_g0_span]
-    struct Sub { int base; std::vector<int> members; };
-    std::vector<Sub> subs;
-    std::vector<char> grouped(m, 0);
-    const int g_g0_span = h->g0_span;
-    if (g_g0_span > 0 && derivs && m > 1 && h->g0_ok && N >= kG0MinPoints && bary_effective_variant(h) == 2) {
+    if (q < 1 || q >= d || h->total > kRotMaxElems || h->dims.n[q] < 2 || h->dims.n[q] > 16) return nullptr;
+    const long sum_n = h->dims.sum_n;
+    long sum_n2 = 0;
+    for (int k = 0; k < d; ++k) sum_n2 += (long)h->dims.n[k] * h->dims.n[k];
+    std::vector<double> nodes((size_t)sum_n), wts((size_t)sum_n), diff((size_t)sum_n2), T((size_t)h->total), TR((size_t)h->total);
+    const DerivedTensor &val = h->cache[std::vector<int>(d, 0)];
+    if (hipMemcpy(nodes.data(), h->d_nodes, sum_n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(wts.data(), h->d_wts, sum_n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(diff.data(), h->d_diff, sum_n2 * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(T.data(), val.plain, h->total * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    int pd[PCX_MAX_DIMS];                       // pd[c] = original dimension at position c of the sub-model
+    pd[0] = q;
+    for (int k = 0, c = 1; k < d; ++k)
+        if (k != q) pd[c++] = k;
+    std::vector<int32_t> nn(d);
+    std::vector<double> rn, rw, rd;
+    long stride[PCX_MAX_DIMS];                  // element strides of the original C-order tensor
+    { long acc = 1; for (int k = d - 1; k >= 0; --k) { stride[k] = acc; acc *= h->dims.n[k]; } }
+    for (int c = 0; c < d; ++c) {
+        const int k = pd[c], n = h->dims.n[k];
+        nn[c] = n;
+        rn.insert(rn.end(), nodes.begin() + h->dims.off[k], nodes.begin() + h->dims.off[k] + n);
+        rw.insert(rw.end(), wts.begin() + h->dims.off[k], wts.begin() + h->dims.off[k] + n);
+        rd.insert(rd.end(), diff.begin() + h->doff[k], diff.begin() + h->doff[k] + (long)n * n);
+    }
+    {   // TR[i_q, i_0, ..] = T[i_0, .., i_q, ..]: an odometer over the sub-model's index, the source offset kept alongside
+        int idx[PCX_MAX_DIMS] = {};
+        long src = 0;
+        for (long e = 0; e < h->total; ++e) {
+            TR[(size_t)e] = T[(size_t)src];
+            for (int c = d - 1; c >= 0; --c) {
+                src += stride[pd[c]];
+                if (++idx[c] < nn[c]) break;
+                src -= stride[pd[c]] * nn[c];
+                idx[c] = 0;
+            }
+        }
+    }
+    pcx_bary *r = nullptr;
+    if (pcx_bary_create(h->device, d, nn.data(), rn.data(), rw.data(), rd.data(), TR.data(), &r) != PCX_OK || !r) return nullptr;
+    if (!r->g0_ok) { pcx_bary_destroy(r); return nullptr; }
+    h->rot[q] = r;
+    h->rot_state[q] = 1;
+    return r;
+}
+
+// a group = the specs one slab GEMM serves: equal orders off dimension q, orders along q in [base, base + span]
+struct BaryGroup { int q; int base; std::vector<int> members; };
+
+// Which specs of a multi-spec launch share a GEMM (caller holds h->mu; may build sub-models).
+//  * span >= 2 (opt-in): specs with equal orders along dimensions 1 .. d-1 and dim-0 orders within [base, base + span].
+//  * then PAIRS: a spec and the spec one order below it along any one dimension q (delta / gamma from the delta
+//    tensor's GEMM, price / vega along the volatility axis, ...), found greedily from the highest total order down,
+//    dimension 0 first; q > 0 runs on the sub-model with q in front (bary_rot), own streams only (its column-permuted
+//    batch lives in the handle).  One differentiation after the contraction per derived member: the accuracy class
+//    measured for price / delta (<= 2e-13 of the scale on 5-D Black-Scholes).
+static void bary_plan_groups(pcx_bary *h, const int32_t *derivs, int m, long N, bool own_stream, std::vector<BaryGroup> &subs,
+                             std::vector<char> &grouped) {
+    const int d = h->dims.d;
+    grouped.assign(m, 0);
+    const int span = h->g0_span;
+    if (!(span > 0 && derivs && m > 1 && N >= kG0MinPoints && bary_effective_variant(h) == 2)) return;
+    auto spec = [&](int s) { return std::vector<int>(derivs + (size_t)s * d, derivs + (size_t)(s + 1) * d); };
+    if (span >= 2 && h->g0_ok) {
         std::map<std::vector<int>, std::vector<int>> by_key;       // orders[1:] -> specs, in column order
         for (int s = 0; s < m; ++s)
             by_key[std::vector<int>(derivs + (size_t)s * d + 1, derivs + (size_t)(s + 1) * d)].push_back(s);
@@ -1170,15 +1235,52 @@ static int bary_launch_specs(pcx_bary *h, const int32_t *derivs, DerivedTensor *
             for (size_t i = 0; i < mem.size();) {
                 const int base = derivs[(size_t)mem[i] * d];
                 size_t e = i;
-                while (e < mem.size() && derivs[(size_t)mem[e] * d] <= base + g_g0_span && e - i < PCX_G0_MAX) ++e;
+                while (e < mem.size() && derivs[(size_t)mem[e] * d] <= base + span && e - i < PCX_G0_MAX) ++e;
                 if (e - i >= 2) {
-                    subs.push_back(Sub{base, std::vector<int>(mem.begin() + i, mem.begin() + e)});
+                    subs.push_back(BaryGroup{0, base, std::vector<int>(mem.begin() + i, mem.begin() + e)});
                     for (size_t q = i; q < e; ++q) grouped[mem[q]] = 1;
                 }
                 i = e;
             }
         }
     }
+    std::map<std::vector<int>, int> first;                          // orders -> first column still on its own
+    std::vector<int> by_order;
+    for (int s = 0; s < m; ++s)
+        if (!grouped[s] && first.emplace(spec(s), s).second) by_order.push_back(s);
+    auto total_order = [&](int s) { int t = 0; for (int k = 0; k < d; ++k) t += derivs[(size_t)s * d + k]; return t; };
+    std::stable_sort(by_order.begin(), by_order.end(), [&](int a, int b) { return total_order(a) > total_order(b); });
+    for (int b : by_order) {
+        if (grouped[b]) continue;
+        std::vector<int> lower = spec(b);
+        for (int q = 0; q < d; ++q) {
+            if (lower[q] < 1) continue;
+            --lower[q];
+            auto it = first.find(lower);
+            ++lower[q];
+            if (it == first.end() || grouped[it->second]) continue;
+            if (q == 0 ? !h->g0_ok : !(own_stream && bary_rot(h, q))) continue;
+            subs.push_back(BaryGroup{q, lower[q] - 1, {it->second, b}});
+            grouped[it->second] = grouped[b] = 1;
+            break;
+        }
+    }
+}
+
+// Multi-spec launch with shared contractions: specs (rows of `derivs`, m x d) one order apart along one dimension --
+// price / delta, delta / gamma, price / vega -- share one slab-packed GEMM over the tensor of the lower order (the
+// reference's own order in vectorized_eval_multi, barycentric.py:1098-1110: contract the other dimensions, then apply
+// D_q); every other spec keeps its own GEMM, launched in runs of consecutive columns.  Large batches on the MFMA
+// kernel only; results of grouped specs differ from the per-spec path by rounding (<= 2e-13 of the scale on 5-D
+// Black-Scholes), as the reference's multi and batch paths do.  Caller holds h->mu.
+static int bary_launch_specs(pcx_bary *h, const int32_t *derivs, DerivedTensor *const *dts, int m,
+                             const double *const *frag_tab, const double *d_pts, long N, double *d_out, long ostride,
+                             long ooff, hipStream_t st, Scratch *split_scratch) {
+    const int d = h->dims.d;
+    std::vector<BaryGroup> subs;
+    std::vector<char> grouped;
+    const bool own_stream = st == h->stream || (h->stream2 && st == h->stream2);
+    bary_plan_groups(h, derivs, m, N, own_stream, subs, grouped);
     // runs of consecutive ungrouped specs: ordinary launches
     for (int s = 0; s < m;) {
         if (grouped[s]) { ++s; continue; }
@@ -1189,26 +1291,74 @@ static int bary_launch_specs(pcx_bary *h, const int32_t *derivs, DerivedTensor *
         if (rc) return rc;
         s = e;
     }
-    for (const Sub &sub : subs) {
-        std::vector<int32_t> bspec(derivs + (size_t)sub.members[0] * d, derivs + (size_t)(sub.members[0] + 1) * d);
-        bspec[0] = sub.base;
+    // the batch in the column order of every sub-model this call uses: one gather per dimension
+    const double *rpts[PCX_MAX_DIMS] = {};
+    {
+        int nq = 0;
+        for (const BaryGroup &sub : subs)
+            if (sub.q > 0 && !rpts[sub.q]) { rpts[sub.q] = d_pts; ++nq; }
+        if (nq) {
+            Scratch &sc = (h->stream2 && st == h->stream2) ? h->s_rot2 : h->s_rot;
+            int rc = sc.reserve((size_t)nq * N * d * sizeof(double));
+            if (rc) return rc;
+            double *dst = (double *)sc.ptr;
+            for (int q = 1; q < d; ++q) {
+                if (!rpts[q]) continue;
+                SliderCols cols{};
+                cols.nc = d;
+                cols.col[0] = q;
+                for (int k = 0, c = 1; k < d; ++k)
+                    if (k != q) cols.col[c++] = k;
+                const long elems = N * d;
+                hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, d_pts, N, d, cols, dst);
+                HIP_TRY(hipGetLastError());
+                rpts[q] = dst;
+                dst += (size_t)N * d;
+            }
+        }
+    }
+    for (const BaryGroup &sub : subs) {
+        pcx_bary *g = sub.q == 0 ? h : h->rot[sub.q];
+        std::vector<int32_t> bspec(d);
+        {   // the lower member's spec in g's dimension order, its order along q first
+            const int32_t *a = derivs + (size_t)sub.members[0] * d;
+            if (sub.q == 0) bspec.assign(a, a + d);
+            else { bspec[0] = a[sub.q]; for (int k = 0, c = 1; k < d; ++k) if (k != sub.q) bspec[c++] = a[k]; }
+            bspec[0] = sub.base;
+        }
+        if (g != h) g->call_mark = g->clock;
         DerivedTensor *base = nullptr;
-        int rc = bary_get_tensor(h, bspec.data(), &base);
+        int rc = bary_get_tensor(g, bspec.data(), &base);
         if (rc) return rc;
-        if ((rc = bary_pack_g0(h, *base))) return rc;
+        if ((rc = bary_pack_g0(g, *base))) return rc;
         BaryG0 gs{};
         gs.nmem = (int)sub.members.size();
-        gs.tps = h->g0_tps;
-        gs.n0 = h->dims.n[0];
+        gs.tps = g->g0_tps;
+        gs.n0 = g->dims.n[0];
         for (int i = 0; i < gs.nmem; ++i) {
-            gs.order[i] = derivs[(size_t)sub.members[i] * d] - sub.base;
+            gs.order[i] = derivs[(size_t)sub.members[i] * d + sub.q] - sub.base;
             gs.col[i] = sub.members[i];
             gs.maxorder = std::max(gs.maxorder, gs.order[i]);
         }
-        rc = (h->g0_nf == 2) ? launch_g0_nf<2>(h, *base, gs, d_pts, N, d_out, ostride, ooff, st)
-                             : launch_g0_nf<3>(h, *base, gs, d_pts, N, d_out, ostride, ooff, st);
+        const double *pp = sub.q == 0 ? d_pts : rpts[sub.q];
+        rc = (g->g0_nf == 2) ? launch_g0_nf<2>(g, *base, gs, pp, N, d_out, ostride, ooff, st)
+                             : launch_g0_nf<3>(g, *base, gs, pp, N, d_out, ostride, ooff, st);
         if (rc) return rc;
     }
+    return PCX_OK;
+}
+
+// GEMM launches a multi-spec call of N points would execute (groups count once); builds what the call would build.
+extern "C" int pcx_bary_count_gemms(pcx_bary *h, const int32_t *derivs, int m, int64_t N, int32_t *gemms_out) {
+    if (!h || !derivs || !gemms_out || m < 1) return fail(PCX_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::vector<BaryGroup> subs;
+    std::vector<char> grouped;
+    bary_plan_groups(h, derivs, m, (long)N, true, subs, grouped);
+    int count = (int)subs.size();
+    for (int s = 0; s < m; ++s) count += !grouped[s];
+    *gemms_out = count;
     return PCX_OK;
 }
 
