@@ -155,17 +155,22 @@ int pcx_tensor_contract_axis(int device, int d, const int32_t *n_nodes, const do
  * {variant used by auto, row tiles, k-steps, lds bytes, points per workgroup, split}.  */
 int pcx_bary_set_kernel(pcx_bary *h, int variant);
 /* Multi-spec batches (pcx_bary_eval_multi_batch[_dev], N >= 65,536 on the MFMA kernel): a spec and the spec ONE order
- * below it along any one dimension q (n_q <= 16) share ONE contraction of the other dimensions and are finished with
- * D_q on the per-node partial sums -- the order of operations of the reference's vectorized_eval_multi
- * (barycentric.py:1098-1110).  Pairs are found from the highest total order down: of price + 5 Greeks, delta / gamma
- * share the delta tensor's GEMM and price / vega one along the volatility axis (4 GEMMs for 6 specs), every member
- * within 2e-13 of the reference's batch results on 5-D Black-Scholes.  q > 0 runs on a copy of the model with q in
- * front, built on first use (tensors up to 2^24 elements; launches on the handle's own streams only).
- * span = 1 is that default (PCX_BARY_G0_SPAN overrides it at load); span = 2 first lets specs up to two dim-0 orders
- * apart share (price / delta / gamma in one GEMM: gamma then 4e-12 from the reference's batch path, as each D_0
- * applied after the contraction amplifies the rounding of the partial sums); span = 0: every spec its own GEMM.
+ * below it along any one dimension q (n_q <= 16) may share ONE contraction of the other dimensions, finished with D_q
+ * on the per-node partial sums -- the order of operations of the reference's vectorized_eval_multi
+ * (barycentric.py:1098-1110).  That rounds differently from the reference's batch path (which differentiates the
+ * tensor first) by a data-dependent amount, so every candidate pair is MEASURED once per handle: a probe batch of
+ * 2,048 points (domain corners, edges, interior) goes through the shared launch and through the spec's own GEMM, and
+ * the pair is formed only when the two agree to `tol` of the batch's scale -- default 3e-13 (PCX_BARY_GROUP_TOL), a
+ * factor of three inside the 1e-12 parity bar.  5-D Black-Scholes: delta out of the price tensor 1e-13 and gamma out
+ * of the delta tensor 1e-13 (shared), vega 7e-13, dV/dT 1e-12, rho 1e-12 (own GEMMs unless tol is raised).
+ * q > 0 runs on a copy of the model with q in front, built on first use (tensors up to 2^24 elements; launches on
+ * the handle's own streams only).  PCX_BARY_PROBE_LOG=1 prints every measurement.
+ * pcx_bary_set_group_span: 1 = the above (default; PCX_BARY_G0_SPAN overrides it at load); 2 first lets specs up to
+ * two dim-0 orders apart share without a probe (price / delta / gamma in one GEMM: gamma then 4e-12 from the
+ * reference's batch path); 0: every spec its own GEMM.
  * pcx_bary_count_gemms: the number of GEMM launches a call with these specs and N would execute.                 */
 int pcx_bary_count_gemms(pcx_bary *h, const int32_t *derivs, int m, int64_t N, int32_t *gemms_out);
+int pcx_bary_set_group_tolerance(pcx_bary *h, double tol);
 int pcx_bary_set_group_span(pcx_bary *h, int span);
 int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
 int pcx_bary_stream(pcx_bary *h, void **stream);

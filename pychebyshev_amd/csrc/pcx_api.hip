@@ -312,6 +312,10 @@ struct pcx_bary {
     pcx_bary *rot[PCX_MAX_DIMS] = {};
     char rot_state[PCX_MAX_DIMS] = {};   // 0 untried, 1 ready, 2 not available
     Scratch s_rot, s_rot2;           // the batch in a sub-model's column order (per staging slot)
+    // what the probe measured for "spec base + e_q out of base's GEMM": |shared - own GEMM| / scale (bary_pair_deviation);
+    // a pair is formed when that is at most group_tol
+    std::map<std::vector<int>, double> pair_dev;
+    double group_tol = 3e-13;
     int lpp = 64;                    // lanes per point in the rows kernel
     bool mfma4_ok = false;           // 4x4x4_4b form available (LDS budget)
     int small_nlp = 0;               // lane-per-point kernel for small tensors: padded last-dim width, 0 = not available
@@ -342,6 +346,11 @@ struct pcx_bary {
 // outside the 1e-12 bar -- so the default is 1 (price + delta share a GEMM, gamma keeps its own);
 // PCX_BARY_G0_SPAN=2 trades that for one GEMM less, 0 switches the grouping off.
 static const int g_g0_span_default = [] { const char *e = getenv("PCX_BARY_G0_SPAN"); return e ? std::min(8, std::max(0, atoi(e))) : 1; }();
+
+// Largest measured deviation of a shared spec from its own GEMM (relative to the probe batch's scale) at which a pair is
+// still formed.  3e-13 keeps a factor of three to the 1e-12 parity bar for whatever batch and pairing order follow
+// (PCX_BARY_GROUP_TOL / pcx_bary_set_group_tolerance override it).
+static const double g_group_tol_default = [] { const char *e = getenv("PCX_BARY_GROUP_TOL"); double v = e ? atof(e) : 0.0; return v > 0.0 ? v : 3e-13; }();
 
 static const long kSmallTensorElems = 4096;   // auto: tensors up to this size run on k_bary_small
 static const int kMaxSpecs = 64;      // derivative specs evaluated by one launch (grid.z)
@@ -454,6 +463,7 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     h->device = device;
     h->dims.d = d;
     h->g0_span = g_g0_span_default;
+    h->group_tol = g_group_tol_default;
     long total = 1, sum_n = 0, sum_n2 = 0;
     for (int k = 0; k < d; ++k) {
         if (n_nodes[k] < 1 || n_nodes[k] > 4096) { delete h; return fail(PCX_ERR_INVALID, "n_nodes[%d]=%d outside [1, 4096]", k, n_nodes[k]); }
@@ -1204,16 +1214,128 @@ static pcx_bary *bary_rot(pcx_bary *h, int q) {
     return r;
 }
 
+// One slab launch: the specs `lower` + rel[i] e_q (lower: a spec in h's dimension order whose order along q is the
+// group's base) into columns col[i].  pp: the batch in the column order of the model that runs it (h for q = 0, else
+// h->rot[q]).  Caller holds h->mu.
+static int bary_launch_group(pcx_bary *h, int q, const int32_t *lower, const int *rel, const int *col, int nmem,
+                             const double *pp, long N, double *d_out, long ostride, long ooff, hipStream_t st) {
+    const int d = h->dims.d;
+    pcx_bary *g = q == 0 ? h : h->rot[q];
+    std::vector<int32_t> bspec(d);
+    if (q == 0) bspec.assign(lower, lower + d);
+    else { bspec[0] = lower[q]; for (int k = 0, c = 1; k < d; ++k) if (k != q) bspec[c++] = lower[k]; }
+    if (g != h) g->call_mark = g->clock;
+    DerivedTensor *base = nullptr;
+    int rc = bary_get_tensor(g, bspec.data(), &base);
+    if (rc) return rc;
+    if ((rc = bary_pack_g0(g, *base))) return rc;
+    BaryG0 gs{};
+    gs.nmem = nmem;
+    gs.tps = g->g0_tps;
+    gs.n0 = g->dims.n[0];
+    for (int i = 0; i < nmem; ++i) {
+        gs.order[i] = rel[i];
+        gs.col[i] = col[i];
+        gs.maxorder = std::max(gs.maxorder, rel[i]);
+    }
+    return (g->g0_nf == 2) ? launch_g0_nf<2>(g, *base, gs, pp, N, d_out, ostride, ooff, st)
+                           : launch_g0_nf<3>(g, *base, gs, pp, N, d_out, ostride, ooff, st);
+}
+
+// How far does the spec lower + e_q come out of lower's GEMM from where its own GEMM puts it?  Differentiating after
+// the contraction rounds differently from the reference's batch path, by an amount that depends on the data and that
+// no cheap bound predicts (5-D Black-Scholes: delta out of the price tensor 1e-13, vega 7e-13, rho 1e-12, vanna out of
+// the delta tensor along sigma 6e-12).  So it is MEASURED, once per handle and (lower, q): a probe batch -- a quarter
+// interior points, a quarter domain corners, half mixtures of lo / hi / interior coordinates: the roundings are
+// largest where the weights are -- goes through the slab launch and through the spec's own GEMM; returned is
+// max |shared - own| / max |own| over it (infinity when the pair cannot run).  Caller holds h->mu; q's model exists.
+static const int kProbePoints = 2048;
+static double bary_pair_deviation(pcx_bary *h, const std::vector<int> &lower, int q) {
+    std::vector<int> key = lower;
+    key.push_back(q);
+    auto it = h->pair_dev.find(key);
+    if (it != h->pair_dev.end()) return it->second;
+    double &dev = h->pair_dev[key];
+    dev = INFINITY;
+    const int d = h->dims.d;
+    // the domain from the outer nodes (Chebyshev points of the first kind: x_0 = mid - half cos(pi / 2n))
+    std::vector<double> nodes((size_t)h->dims.sum_n);
+    if (hipMemcpy(nodes.data(), h->d_nodes, nodes.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return dev;
+    std::vector<double> lo(d), hi(d);
+    for (int k = 0; k < d; ++k) {
+        const int n = h->dims.n[k];
+        const double a = nodes[h->dims.off[k]], b = nodes[h->dims.off[k] + n - 1];
+        const double half = n > 1 ? 0.5 * (b - a) / std::cos(3.14159265358979323846 / (2.0 * n)) : 0.0;
+        lo[k] = 0.5 * (a + b) - half;
+        hi[k] = 0.5 * (a + b) + half;
+    }
+    const long N = kProbePoints;
+    std::vector<double> P((size_t)N * d);
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { state = state * 6364136223846793005ull + 1442695040888963407ull; return (uint32_t)(state >> 33); };
+    for (long p = 0; p < N; ++p) {
+        const int mode = (int)(p % 4);              // 0 interior, 1 corner, 2 / 3 a mix of lo, hi and interior coordinates
+        for (int k = 0; k < d; ++k) {
+            const uint32_t r = rnd();
+            const double uni = lo[k] + (hi[k] - lo[k]) * ((double)(r >> 8) / 8388608.0);
+            const int pick = mode == 0 ? 2 : (mode == 1 ? (int)(r & 1) : (int)(r % 3));
+            P[(size_t)p * d + k] = pick == 0 ? lo[k] : (pick == 1 ? hi[k] : uni);
+        }
+    }
+    DevBuf dp, dr, dout;
+    if (dp.alloc(P.size() * sizeof(double)) || dr.alloc(P.size() * sizeof(double)) || dout.alloc((size_t)N * 2 * sizeof(double))) return dev;
+    if (hipMemcpy(dp.p, P.data(), P.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return dev;
+    const double *gp = dp.as<double>();
+    if (q > 0) {
+        SliderCols cols{};
+        cols.nc = d;
+        cols.col[0] = q;
+        for (int k = 0, c = 1; k < d; ++k)
+            if (k != q) cols.col[c++] = k;
+        hipLaunchKernelGGL(k_gather_columns, dim3((unsigned)((N * d + 255) / 256)), dim3(256), 0, h->stream, dp.as<double>(), N, d,
+                           cols, dr.as<double>());
+        gp = dr.as<double>();
+    }
+    std::vector<int32_t> lspec(lower.begin(), lower.end()), uspec(lower.begin(), lower.end());
+    ++uspec[q];
+    const int rel = 1, col = 0;
+    if (bary_launch_group(h, q, lspec.data(), &rel, &col, 1, gp, N, dout.as<double>(), 2, 0, h->stream)) return dev;
+    DerivedTensor *own = nullptr;
+    if (bary_get_tensor(h, uspec.data(), &own)) return dev;
+    DerivedTensor *one[1] = {own};
+    if (bary_launch(h, one, 1, own->slot, dp.as<double>(), N, dout.as<double>(), 2, 1, h->stream, &h->s_partial)) return dev;
+    std::vector<double> R((size_t)N * 2);
+    if (hipStreamSynchronize(h->stream) != hipSuccess ||
+        hipMemcpy(R.data(), dout.p, R.size() * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) {
+        (void)hipGetLastError();
+        return dev;
+    }
+    double scale = 0.0, diff = 0.0;
+    for (long p = 0; p < N; ++p) {
+        scale = std::max(scale, std::fabs(R[2 * p + 1]));
+        diff = std::max(diff, std::fabs(R[2 * p] - R[2 * p + 1]));
+    }
+    if (std::isfinite(diff) && std::isfinite(scale)) dev = scale > 0.0 ? diff / scale : (diff == 0.0 ? 0.0 : INFINITY);
+    static const bool log = getenv("PCX_BARY_PROBE_LOG") != nullptr;
+    if (log) {
+        fprintf(stderr, "[pcx] pair probe (");
+        for (int k = 0; k < d; ++k) fprintf(stderr, "%d%s", lower[k], k + 1 < d ? "," : "");
+        fprintf(stderr, ") + e_%d out of one GEMM: %.3g of the scale from its own GEMM (tolerance %.3g)\n", q, dev, h->group_tol);
+    }
+    return dev;
+}
+
 // a group = the specs one slab GEMM serves: equal orders off dimension q, orders along q in [base, base + span]
 struct BaryGroup { int q; int base; std::vector<int> members; };
 
-// Which specs of a multi-spec launch share a GEMM (caller holds h->mu; may build sub-models).
-//  * span >= 2 (opt-in): specs with equal orders along dimensions 1 .. d-1 and dim-0 orders within [base, base + span].
+// Which specs of a multi-spec launch share a GEMM (caller holds h->mu; may build sub-models and run probes).
+//  * span >= 2 (opt-in, not probed): specs with equal orders along dimensions 1 .. d-1 and dim-0 orders within
+//    [base, base + span].
 //  * then PAIRS: a spec and the spec one order below it along any one dimension q (delta / gamma from the delta
 //    tensor's GEMM, price / vega along the volatility axis, ...), found greedily from the highest total order down,
 //    dimension 0 first; q > 0 runs on the sub-model with q in front (bary_rot), own streams only (its column-permuted
-//    batch lives in the handle).  One differentiation after the contraction per derived member: the accuracy class
-//    measured for price / delta (<= 2e-13 of the scale on 5-D Black-Scholes).
+//    batch lives in the handle).  A pair is formed only when the probe has MEASURED the derived member within
+//    h->group_tol of its own GEMM (bary_pair_deviation).
 static void bary_plan_groups(pcx_bary *h, const int32_t *derivs, int m, long N, bool own_stream, std::vector<BaryGroup> &subs,
                              std::vector<char> &grouped) {
     const int d = h->dims.d;
@@ -1260,6 +1382,10 @@ static void bary_plan_groups(pcx_bary *h, const int32_t *derivs, int m, long N, 
             ++lower[q];
             if (it == first.end() || grouped[it->second]) continue;
             if (q == 0 ? !h->g0_ok : !(own_stream && bary_rot(h, q))) continue;
+            --lower[q];
+            const double dev = bary_pair_deviation(h, lower, q);
+            ++lower[q];
+            if (!(dev <= h->group_tol)) continue;
             subs.push_back(BaryGroup{q, lower[q] - 1, {it->second, b}});
             grouped[it->second] = grouped[b] = 1;
             break;
@@ -1318,31 +1444,16 @@ static int bary_launch_specs(pcx_bary *h, const int32_t *derivs, DerivedTensor *
         }
     }
     for (const BaryGroup &sub : subs) {
-        pcx_bary *g = sub.q == 0 ? h : h->rot[sub.q];
-        std::vector<int32_t> bspec(d);
-        {   // the lower member's spec in g's dimension order, its order along q first
-            const int32_t *a = derivs + (size_t)sub.members[0] * d;
-            if (sub.q == 0) bspec.assign(a, a + d);
-            else { bspec[0] = a[sub.q]; for (int k = 0, c = 1; k < d; ++k) if (k != sub.q) bspec[c++] = a[k]; }
-            bspec[0] = sub.base;
+        std::vector<int32_t> lower(derivs + (size_t)sub.members[0] * d, derivs + (size_t)(sub.members[0] + 1) * d);
+        lower[sub.q] = sub.base;
+        int rel[PCX_G0_MAX], col[PCX_G0_MAX];
+        const int nmem = (int)sub.members.size();
+        for (int i = 0; i < nmem; ++i) {
+            rel[i] = derivs[(size_t)sub.members[i] * d + sub.q] - sub.base;
+            col[i] = sub.members[i];
         }
-        if (g != h) g->call_mark = g->clock;
-        DerivedTensor *base = nullptr;
-        int rc = bary_get_tensor(g, bspec.data(), &base);
-        if (rc) return rc;
-        if ((rc = bary_pack_g0(g, *base))) return rc;
-        BaryG0 gs{};
-        gs.nmem = (int)sub.members.size();
-        gs.tps = g->g0_tps;
-        gs.n0 = g->dims.n[0];
-        for (int i = 0; i < gs.nmem; ++i) {
-            gs.order[i] = derivs[(size_t)sub.members[i] * d + sub.q] - sub.base;
-            gs.col[i] = sub.members[i];
-            gs.maxorder = std::max(gs.maxorder, gs.order[i]);
-        }
-        const double *pp = sub.q == 0 ? d_pts : rpts[sub.q];
-        rc = (g->g0_nf == 2) ? launch_g0_nf<2>(g, *base, gs, pp, N, d_out, ostride, ooff, st)
-                             : launch_g0_nf<3>(g, *base, gs, pp, N, d_out, ostride, ooff, st);
+        int rc = bary_launch_group(h, sub.q, lower.data(), rel, col, nmem, sub.q == 0 ? d_pts : rpts[sub.q], N, d_out, ostride,
+                                   ooff, st);
         if (rc) return rc;
     }
     return PCX_OK;
@@ -1654,6 +1765,14 @@ extern "C" int pcx_bary_set_group_span(pcx_bary *h, int span) {
     if (span < 0 || span > 8) return fail(PCX_ERR_INVALID, "span %d outside [0, 8]", span);
     std::lock_guard<std::mutex> lk(h->mu);
     h->g0_span = span;
+    return PCX_OK;
+}
+
+extern "C" int pcx_bary_set_group_tolerance(pcx_bary *h, double tol) {
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (!(tol >= 0.0)) return fail(PCX_ERR_INVALID, "tolerance must be >= 0");
+    std::lock_guard<std::mutex> lk(h->mu);
+    h->group_tol = tol;
     return PCX_OK;
 }
 

@@ -333,19 +333,34 @@ def test_dim0_groups_share_one_contraction_and_match_reference(bs5d):
         assert m.lib.pcx_bary_count_gemms(m.handle, _lib.p_i32(_lib.i32(np.asarray(sp).reshape(-1))), len(sp), n, _lib.p_i32(out)) == 0
         return int(out[0])
 
+    # a pair is formed only when the probe has measured the derived member within the tolerance (default 3e-13) of its
+    # own GEMM: delta / gamma share (1e-13), vega (7e-13), dV/dT and rho (1e-12) out of the price GEMM do not -- until
+    # the caller raises the tolerance
     six = [[0, 0, 0, 0, 0], [1, 0, 0, 0, 0], [2, 0, 0, 0, 0], [0, 0, 0, 1, 0], [0, 0, 1, 0, 0], [0, 0, 0, 0, 1]]
-    assert gemms(six, 1_000_000) == 4 and gemms(six, 1000) == 6          # delta/gamma, price/vega; small batches: per spec
-    assert gemms([[0] * 5, [0, 0, 0, 0, 1]], 100_000) == 1 and gemms([[0] * 5, [0, 1, 0, 1, 0]], 100_000) == 2
+    assert gemms(six, 1_000_000) == 5 and gemms(six, 1000) == 6           # small batches: per spec
+    assert gemms([[0] * 5, [1, 0, 0, 0, 0]], 100_000) == 1 and gemms([[0] * 5, [0, 1, 0, 1, 0]], 100_000) == 2
+    assert gemms([[0] * 5, [0, 0, 0, 0, 1]], 100_000) == 2                # rho: 1e-12 from its own GEMM on the probe
+    assert m.lib.pcx_bary_set_group_tolerance(m.handle, 1e-12) == 0
+    try:
+        assert gemms(six, 1_000_000) == 4                                  # + price / vega
+        loose = c.vectorized_eval_multi_batch(pts, six)
+        for col, s in enumerate(six):
+            assert_parity(loose[:n0, col], g["out"][specs.index(s)], 1e-12, f"tolerance 1e-12 {s}", spec_point_tol(s))
+    finally:
+        assert m.lib.pcx_bary_set_group_tolerance(m.handle, 3e-13) == 0
+    assert m.lib.pcx_bary_set_group_tolerance(m.handle, -1.0) == _lib.PCX_ERR_INVALID
 
 
 @pytest.mark.parametrize("shape,shares", [((7, 6, 9, 8, 5), True), ((11, 11, 11, 11), False), ((16, 12, 10, 14), None),
                                           ((6, 5, 4, 7, 3, 6), None), ((8, 8, 8, 8, 8), True)])
 def test_pairs_along_any_dimension_share_one_contraction(oracle_mod, shape, shares):
     """Round 3: a spec and the spec one order below it along dimension q share a slab GEMM -- for q > 0 on a copy of the
-    model with q in front (built on first use) and the batch with its columns in that order.  Random tensors, every
-    first derivative next to the value, second derivatives and mixed partials, N = 70,001 (ragged): every column
-    <= 1e-12 of the oracle and within 5e-13 of the per-spec path; fewer GEMMs than specs where the shape has a slab plan
-    (11^4 has none: its plan folds two dimensions into K and leaves 11 rows per slab; then every spec keeps its GEMM)."""
+    model with q in front (built on first use) and the batch with its columns in that order -- when the probe measures the
+    derived member within the tolerance of its own GEMM.  Random tensors (noise: pairs pass the probe at 1e-12 of the
+    derivative tensor's own scale, set here), every first derivative next to the value, second derivatives and mixed
+    partials, N = 70,001 (ragged): every column <= 1e-12 of the oracle and within 5e-13 of the per-spec path; fewer GEMMs
+    than specs where the shape has a slab plan (11^4 has none: its plan folds two dimensions into K and leaves 11 rows
+    per slab; then every spec keeps its GEMM)."""
     rng = np.random.default_rng(sum(shape))
     d = len(shape)
     T = rng.standard_normal(shape)
@@ -354,6 +369,7 @@ def test_pairs_along_any_dimension_share_one_contraction(oracle_mod, shape, shar
     om = _oracle_model(oracle_mod, c)
     _set_kernel(c, 2)
     m = c._model()
+    assert m.lib.pcx_bary_set_group_tolerance(m.handle, 1e-12) == 0
     N = 70_001
     pts = np.column_stack([rng.uniform(lo, hi, N) for lo, hi in dom])
     pts[0] = [c.nodes[k][-1] for k in range(d)]
