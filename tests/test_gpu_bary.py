@@ -186,6 +186,9 @@ def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     pts = np.column_stack([rng.uniform(lo, hi, 777) for lo, hi in dom])
     for k in range(d):                      # a few rows exactly on nodes
         pts[k, k] = c.nodes[k][rng.integers(0, shape[k])]
+    pts[-1] = [lo for lo, hi in dom]        # domain corners: every weight at its largest
+    pts[-2] = [hi for lo, hi in dom]
+    pts[-3] = [lo if k % 2 else hi for k, (lo, hi) in enumerate(dom)]
     om = _oracle_model(oracle_mod, c)
     specs = [[0] * d]
     if all(v > 2 for v in shape):
@@ -830,6 +833,10 @@ def test_lane_per_point_kernel_for_small_tensors(oracle_mod, shape):
         pts[0] = [c.nodes[k][-1] for k in range(d)]                 # a grid point
         if npts > 2:
             pts[2, d - 1] = c.nodes[d - 1][0]                         # exact node in the register dimension only
+        if npts > 60:                                                 # domain corners: every weight at its largest
+            pts[-1] = [lo for lo, hi in dom]
+            pts[-2] = [hi for lo, hi in dom]
+            pts[-3] = [lo if k % 2 else hi for k, (lo, hi) in enumerate(dom)]
         for s in specs:
             ref = oracle_mod.bary_eval_batch(om, pts, s)
             got = c.vectorized_eval_batch(pts, s)
@@ -966,6 +973,10 @@ def test_square_trailing_lane_per_point_kernel(oracle_mod, shape):
             pts[2, d - 1] = c.nodes[d - 1][0]                         # exact node in one register dimension
             pts[3, d - 2] = c.nodes[d - 2][1] + 3e-15                 # near-node in the other
             pts[4, 0] = c.nodes[0][-1] - 4e-15 * max(1.0, abs(c.nodes[0][-1]))
+        if npts > 60:                                                 # domain corners: every weight at its largest
+            pts[-1] = [lo for lo, hi in dom]
+            pts[-2] = [hi for lo, hi in dom]
+            pts[-3] = [lo if k % 2 else hi for k, (lo, hi) in enumerate(dom)]
         multi = c.vectorized_eval_multi_batch(pts, specs)
         for j, s in enumerate(specs):
             ref = oracle_mod.bary_eval_batch(om, pts, s)
