@@ -48,6 +48,10 @@ def bary_case(rng, stats):
     for _ in range(min(npts, 4)):                                  # exact-node coordinates
         k = int(rng.integers(d))
         pts[int(rng.integers(npts)), k] = c.nodes[k][int(rng.integers(shape[k]))]
+    for _ in range(min(npts // 4, 6)):                             # domain corners and edges: every weight at its largest
+        pick = rng.integers(0, 3 if rng.random() < 0.5 else 2, d)
+        row = int(rng.integers(npts))
+        pts[row] = [(lo, hi, pts[row, k])[int(pick[k])] for k, (lo, hi) in enumerate(dom)]
     spec = [0] * d
     if rng.random() < 0.6:
         for _ in range(int(rng.integers(1, 3))):
@@ -231,6 +235,9 @@ def group_case(rng, stats):
     pts = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
     pts[0] = [c.nodes[k][-1] for k in range(d)]
     pts[1, 0] = c.nodes[0][0]
+    for row in range(2, 40):                                       # domain corners and edges (rows 0..63 are always checked)
+        pick = rng.integers(0, 3 if row % 2 else 2, d)
+        pts[row] = [(lo, hi, pts[row, k])[int(pick[k])] for k, (lo, hi) in enumerate(dom)]
     got = c.vectorized_eval_multi_batch(pts, specs)
     mdl.lib.pcx_bary_set_group_span(mdl.handle, 0)
     plain = c.vectorized_eval_multi_batch(pts, specs)
