@@ -927,6 +927,10 @@ __device__ __forceinline__ double bary_sq_block(pcx_cptr Tb, const double (&b1)[
                 if (r & 1) t1 = __builtin_fma(b1[i + r], s[r], t1);
                 else t0 = __builtin_fma(b1[i + r], s[r], t0);
             }
+        // (a scheduling barrier here -- one pass at a time -- removes the v_writelane / v_readlane pairs hipcc parks hoisted
+        // scalar loads in, and is worth 5..8 % in tools/bary_sq_lab.hip's stripped-down kernel; in THIS kernel it costs up
+        // to 38 % (32^3 0.48 -> 0.30, 24^3 0.54 -> 0.40; 13^3 +9 %): the hoisted loads are what hides the scalar-load
+        // latency.  Measured, not kept.)
     }
     return t0 + t1;
 }
