@@ -882,8 +882,11 @@ def test_lane_per_point_kernel_large_batches(oracle_mod, shape):
         assert np.array_equal(multi[:, 1], big)
 
 
-@pytest.mark.parametrize("shape", [(12, 12), (9, 7, 6), (16,), (5, 4, 3, 6), (30, 30), (40,), (3, 26, 26), (48, 3)])
-@pytest.mark.parametrize("variant", [4, 5])
+_NEAR_NODE_SHAPES = [(12, 12), (9, 7, 6), (16,), (5, 4, 3, 6), (30, 30), (40,), (3, 26, 26), (48, 3)]
+
+
+@pytest.mark.parametrize("shape,variant", [(s, 4) for s in _NEAR_NODE_SHAPES] +
+                         [(s, 5) for s in _NEAR_NODE_SHAPES if len(s) >= 2 and s[-1] == s[-2]])     # k_bary_sq: square trailing dimensions
 def test_near_node_points_through_the_lane_per_point_kernels(oracle_mod, shape, variant):
     """Coordinates within 1e-14 of a node but not on it (node +- 3e-15, as g2's `near` rows,
     tests/golden/generate_golden.py:103-105): the reference returns the node's slice there
@@ -891,8 +894,6 @@ def test_near_node_points_through_the_lane_per_point_kernels(oracle_mod, shape, 
     weights; round 2 evaluated the interpolant at x, O(1e-14 |f'|) away -- with 30 or 40 noisy nodes that is 1e-11
     and would fail here).  Against the oracle, which applies the reference's rule literally: 1e-13 for values."""
     d = len(shape)
-    if variant == 5 and not (d >= 2 and shape[-1] == shape[-2]):
-        pytest.skip("square trailing dimensions only")
     rng = np.random.default_rng(100 + sum(shape))
     T = rng.standard_normal(shape)
     dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-3, 3, d), rng.uniform(0.5, 3, d))]
