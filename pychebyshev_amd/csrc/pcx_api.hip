@@ -1582,8 +1582,12 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
     }
     // Two staging slots on two streams: the H2D copy of chunk i+1 and the D2H copy of chunk i-1
     // overlap the kernel of chunk i.  A slot is reused only after its stream has drained.
-    const int64_t chunk = (N >= 2 * kPipeChunkPoints) ? kPipeChunkPoints : kChunkPoints;
-    if (chunk == kPipeChunkPoints && !h->stream2)
+    // pieces of 2^18 points (10 MB of 5-D coordinates); low-dimensional models take more points per piece so that a
+    // piece still moves ~10 MB (12 x 12 at 2x10^7 points: 4 MB pieces ran the path at 13 GB/s)
+    const int64_t piece = std::min<int64_t>((int64_t)1 << 21, std::max<int64_t>(kPipeChunkPoints, (((int64_t)10 << 20) / (d * 8)) & ~(int64_t)65535));
+    const bool piped = N >= 2 * piece;
+    const int64_t chunk = piped ? piece : kChunkPoints;
+    if (piped && !h->stream2)
         HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     // Copies from/to pageable memory block the host until their stream reaches them, so the
     // result copy of chunk i-1 is issued only after chunk i's upload and launch are queued.
@@ -1591,17 +1595,17 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
     int64_t prev_start = -1;
     long prev_cnt = 0;
     auto download = [&](int sl, int64_t start, long cnt) -> int {
-        const bool second = (chunk == kPipeChunkPoints) && sl == 1;
+        const bool second = piped && sl == 1;
         HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, (second ? h->s_out2 : h->s_out).ptr,
                                (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
         return PCX_OK;
     };
     // a short first piece (one round of workgroups) so that the first kernel starts after 2.6 MB instead of
     // 10 MB of upload: nothing overlaps the first upload
-    const int64_t first_piece = (chunk == kPipeChunkPoints) ? (1 << 16) : chunk;
+    const int64_t first_piece = piped ? (1 << 16) : chunk;
     for (int64_t start = 0, step = first_piece; start < N; start += step, step = chunk, slot ^= 1) {
         long cnt = (long)std::min<int64_t>(step, N - start);
-        const bool second = (chunk == kPipeChunkPoints) && slot == 1;
+        const bool second = piped && slot == 1;
         hipStream_t st = second ? h->stream2 : h->stream;
         Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
         int rc = sp.reserve((size_t)cnt * d * sizeof(double));
@@ -1613,7 +1617,7 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         rc = bary_launch_specs(h, derivs, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial);
         if (rc) return rc;
         if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
-        if (chunk != kPipeChunkPoints) {          // single slot: drain before its buffers are reused
+        if (!piped) {                             // single slot: drain before its buffers are reused
             if ((rc = download(slot, start, cnt))) return rc;
             HIP_TRY(hipStreamSynchronize(st));
             prev_start = -1;
