@@ -1659,15 +1659,52 @@ extern "C" int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t
 // ---------------------------------------------------------------------------------
 struct HostPin {
     void *a = nullptr, *b = nullptr;
-    void pin(const void *p, size_t bytes, void **slot) {
-        if (p && bytes && hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess) *slot = const_cast<void *>(p);
-        else (void)hipGetLastError();          // already registered / not page-lockable: the pageable path still works
+    // true when [p, p + bytes) is page-locked afterwards: registered here (released by the destructor) or already
+    // page-locked by the caller (pcx_host_register, hipHostMalloc)
+    bool pin(const void *p, size_t bytes, void **slot) {
+        if (!p || !bytes) return true;
+        hipPointerAttribute_t at{};
+        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) {
+            hipPointerAttribute_t ae{};
+            if (hipPointerGetAttributes(&ae, (const char *)p + bytes - 1) == hipSuccess && ae.type == hipMemoryTypeHost) return true;
+        }
+        (void)hipGetLastError();
+        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess) {
+            *slot = const_cast<void *>(p);
+            return true;
+        }
+        (void)hipGetLastError();
+        return false;
     }
     ~HostPin() {
         if (a) (void)hipHostUnregister(a);
         if (b) (void)hipHostUnregister(b);
     }
 };
+
+// Several host threads may copy between ONE pageable allocation and their devices only when that allocation is
+// page-locked as a whole.  From pageable memory the runtime page-locks each copy's range on the fly, rounded to pages;
+// two threads working on adjacent row blocks then share the boundary page, and a copy that found the neighbour's
+// lock went on past its end: a GPU memory access fault in the middle of the caller's result array (found by
+// tools/soak.py --pin, round 3: barycentric value, 2^19 rows over two handles).  So the fan-out runs only over
+// page-locked arrays: `pin` registers them for the call; when that is declined or fails, the whole batch goes
+// through the first handle.
+static bool fanout_arrays_locked(HostPin &hp, int pin, const void *in, size_t in_bytes, void *out, size_t out_bytes) {
+    if (!pin) {
+        hipPointerAttribute_t ai{}, ao{};
+        const bool ok = hipPointerGetAttributes(&ai, in) == hipSuccess && ai.type == hipMemoryTypeHost &&
+                        hipPointerGetAttributes(&ao, out) == hipSuccess && ao.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        return ok;
+    }
+    const bool ok_in = hp.pin(in, in_bytes, &hp.a);
+    const bool ok_out = hp.pin(out, out_bytes, &hp.b);
+    static const bool log = getenv("PCX_FANOUT_LOG") != nullptr;
+    if (log && !(ok_in && ok_out))
+        fprintf(stderr, "[pcx] fan-out: could not page-lock the caller's arrays (points %d, results %d): one handle takes the batch\n",
+                (int)ok_in, (int)ok_out);
+    return ok_in && ok_out;
+}
 
 template <typename Fn>
 static int fan_out(int n_handles, int64_t N, Fn &&block_call) {
@@ -1702,11 +1739,9 @@ extern "C" int pcx_bary_group_eval_multi_batch(pcx_bary *const *handles, int n_h
     if (n_handles == 1 || N == 0) return bary_eval_host(handles[0], pts, N, derivs, m, out);
     const int d = handles[0]->dims.d;
     HostPin hp;
-    if (pin) {
-        HIP_TRY(hipSetDevice(handles[0]->device));
-        hp.pin(pts, (size_t)N * d * sizeof(double), &hp.a);
-        hp.pin(out, (size_t)N * m * sizeof(double), &hp.b);
-    }
+    HIP_TRY(hipSetDevice(handles[0]->device));
+    if (!fanout_arrays_locked(hp, pin, pts, (size_t)N * d * sizeof(double), out, (size_t)N * m * sizeof(double)))
+        return bary_eval_host(handles[0], pts, N, derivs, m, out);
     return fan_out(n_handles, N, [&](int g, int64_t lo, int64_t cnt) {
         return bary_eval_host(handles[g], pts + (size_t)lo * d, cnt, derivs, m, out + (size_t)lo * m);
     });
@@ -2949,11 +2984,9 @@ extern "C" int pcx_tt_group_eval_batch(pcx_tt *const *handles, int n_handles, co
     if (n_handles == 1 || N == 0) return pcx_tt_eval_batch(handles[0], pts, N, out);
     const int d = handles[0]->dims.d;
     HostPin hp;
-    if (pin) {
-        HIP_TRY(hipSetDevice(handles[0]->device));
-        hp.pin(pts, (size_t)N * d * sizeof(double), &hp.a);
-        hp.pin(out, (size_t)N * sizeof(double), &hp.b);
-    }
+    HIP_TRY(hipSetDevice(handles[0]->device));
+    if (!fanout_arrays_locked(hp, pin, pts, (size_t)N * d * sizeof(double), out, (size_t)N * sizeof(double)))
+        return pcx_tt_eval_batch(handles[0], pts, N, out);
     return fan_out(n_handles, N, [&](int g, int64_t lo, int64_t cnt) {
         return pcx_tt_eval_batch(handles[g], pts + (size_t)lo * d, cnt, out + lo);
     });

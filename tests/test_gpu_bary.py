@@ -946,6 +946,25 @@ def test_single_process_fan_out_over_device_handles(bs5d):
                                                  _lib.p_f64(out), 0) == _lib.PCX_ERR_INVALID
 
 
+def test_fan_out_with_result_arrays_that_grow_between_calls(bs5d):
+    """Round 3: the pinned two-handle path faulted the GPU at the first call whose result array was larger than the
+    previous call's (2^18 -> 2^19 rows: NumPy grows the block in place on the heap, and the caller's arrays are registered
+    for each call; tools/soak.py --pin found it).  The sequence that did it, against the single-handle results; since the fix
+    the arrays are checked (and taken as they are when the caller has page-locked them) before they are registered, and a
+    batch whose arrays cannot be page-locked goes through one handle."""
+    c, g = bs5d
+    rng = np.random.default_rng(5)
+    big = np.column_stack([rng.uniform(lo, hi, 1 << 20) for lo, hi in F.BS5_DOMAIN])
+    one = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES).to_device(0)
+    for rep in range(2):
+        for lg in (17, 18, 19, 20):
+            n = 1 << lg
+            fan = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES).to_device(devices=[0, 0])
+            y = fan.vectorized_eval_batch(big[:n], [0] * 5)
+            assert np.array_equal(y, one.vectorized_eval_batch(big[:n], [0] * 5)), (rep, lg)
+            assert np.array_equal(fan.vectorized_eval_batch(big[:n], [0] * 5), y)
+
+
 @pytest.mark.parametrize("shape", [(20, 20, 20), (7, 7), (5, 9, 9), (3, 4, 6, 6), (24, 24), (32, 32), (2, 17, 17), (4, 4),
                                    (13, 13, 13), (6, 5, 11, 11), (30, 30), (3, 26, 26)])
 def test_square_trailing_lane_per_point_kernel(oracle_mod, shape):

@@ -3,11 +3,8 @@
 12 x 12 tensor, and the 5-D barycentric model (value, six Greeks).  Written to decide whether a same-device twin should be the
 default for large pageable batches (it is not: +16 % for TT, +80 % for 12 x 12 at 2^24 points, nothing below 2^19).
 
-OPEN ISSUE (round 3): ONE run of this sweep ended in a GPU memory access fault in its 2^19 row (which of the eight
-sub-runs is unknown: the row prints at its end).  Each of the eight cases then ran alone, in its own process, 4 handle
-re-creations x 5 calls, without a fault.  What the sweep does and the isolated runs do not: slices of 2^24-row arrays, four
-models alive in one process, alternating pageable and page-locked transfers over the same host pages, ~60 handle
-re-creations.  Not root-caused; see DESIGN.md section 9.  Do not loop this script on a shared GPU.
+Round 3: one run of this sweep ended in a GPU memory access fault in its 2^19 row; tools/soak.py --pin attributed it to the
+two-handle path with the caller's arrays registered for the call; fixed in pcx_api.hip (fanout_arrays_locked).
 """
 import numpy as np, sys, time
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests/golden'); sys.path.insert(0,'/root/repo/tools')
