@@ -123,9 +123,12 @@ int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t N, const i
 /* The same over SEVERAL handles of one process (the same model created on several devices -- the
  * "devices[] list" of a drop-in create): handle g evaluates the contiguous row
  * block [g ceil(N/G), ...) on its own device from its own host thread, every download lands in its slice of
- * `out`; no collective.  pin != 0: the caller's arrays are page-locked for the call (asynchronous copies at
- * PCIe rate).  Replaces the reference's single-process vectorized_eval_batch (barycentric.py:992) when the
- * process sees more than one GPU.                                                          */
+ * `out`; no collective.  The blocks run concurrently only over PAGE-LOCKED arrays: pin != 0 registers the caller's
+ * arrays for the call (arrays the caller has page-locked itself -- pcx_host_register -- are taken as they are);
+ * with pin = 0 and pageable arrays, or when the registration fails, the whole batch goes through handles[0]
+ * (several host threads never copy to or from one pageable allocation; PCX_FANOUT_LOG=1 reports the fallback).
+ * Replaces the reference's single-process vectorized_eval_batch (barycentric.py:992) when the process sees more
+ * than one GPU.                                                                                              */
 int pcx_bary_group_eval_multi_batch(pcx_bary *const *handles, int n_handles, const double *pts, int64_t N,
                                     const int32_t *derivs, int m, double *out, int pin);
 /* Device-resident form: d_pts (N x d) and d_out (N x m) in HBM; enqueues on `stream`
