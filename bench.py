@@ -30,8 +30,9 @@ Also on the JSON line:
                HIP events on the launch stream, vs the FP64 MFMA peak; `traffic` is the
                HBM bytes per launch from the committed PMC profile (cached; see
                traffic_source), not collected in this run.
-  end_to_end   the host-pointer entry point on the same batch (H2D + kernel + D2H), with the PCIe GB/s, and
-               the same call on caller arrays page-locked beforehand (pcx_host_register).
+  end_to_end   the host-pointer entry point on the same batch (H2D + kernel + D2H) through the Python method (a fresh
+               result array per call), with the PCIe GB/s; `preallocated`: the C-ABI call into result arrays the
+               caller owns; `page_locked`: on caller arrays page-locked beforehand (pcx_host_register).
   greeks, tt, tt10d, c1
                companions: config 4 (6 derivative specs in ONE multi-spec call: delta and gamma share a
                GEMM -- the pairs the library's accuracy probe admits at 3e-13 -- roofline on the 5 executed
@@ -656,7 +657,19 @@ def run_rank(args) -> int:
                "what": "host-pointer C-ABI call on the same batch: pageable H2D + kernel + D2H inclusive"}
         if hasattr(wl, "host_eval_into"):
             try:
+                # the same C-ABI call into result arrays the caller already owns (touched once): what is left when the
+                # host's page faults on a freshly allocated result array are taken out
                 outs = wl.host_outputs(len(pts))
+                for a in outs:
+                    a.fill(0.0)
+                wl.host_eval_into(pts, outs)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    wl.host_eval_into(pts, outs)
+                dtq = (time.perf_counter() - t0) / reps
+                out["preallocated"] = {"value": len(pts) * wl.evals_per_point / dtq, "ms_per_call": dtq * 1e3,
+                                       "pcie_gb_per_s": moved / dtq / 1e9,
+                                       "what": "pageable arrays again, results into arrays the caller allocated (and touched) before"}
                 regs = []
                 t0 = time.perf_counter()
                 for a in [pts] + outs:

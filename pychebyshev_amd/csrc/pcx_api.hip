@@ -5,9 +5,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <mutex>
 #include <new>
@@ -264,6 +266,72 @@ struct Pinned {
         if (out) (void)hipHostFree(out);
         in = out = nullptr;
     }
+};
+
+// A copy from or to PAGEABLE caller memory blocks the calling thread until it is done, so a single host thread runs a
+// piece's upload and the previous piece's download one after the other (40 + 8 bytes per TT point at the pageable rate:
+// the whole host-pointer path).  The downloads of a pipelined batch therefore go to a helper thread: it issues each one
+// on the piece's own stream -- behind that piece's kernel -- while the caller's thread is inside the next upload.  The
+// two threads touch different allocations (points / results).  Jobs are issued in order; the caller's thread waits for
+// job i to have been ISSUED before it queues anything else on that stream or frees its source buffer.
+struct Downloader {
+    struct Job { void *dst; const void *src; size_t bytes; hipStream_t st; };
+    int device;
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Job> q;
+    long pushed = 0, issued = 0;
+    bool stop = false;
+    int rc = PCX_OK;
+    std::string err;
+    explicit Downloader(int dev) : device(dev) {}
+    Downloader(const Downloader &) = delete;
+    Downloader &operator=(const Downloader &) = delete;
+    void run() {
+        (void)hipSetDevice(device);
+        for (;;) {
+            Job j;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                j = q.front();
+                q.pop_front();
+            }
+            hipError_t e = hipSuccess;
+            if (rc == PCX_OK) e = hipMemcpyAsync(j.dst, j.src, j.bytes, hipMemcpyDeviceToHost, j.st);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (e != hipSuccess && rc == PCX_OK) { rc = PCX_ERR_HIP; err = std::string("download: ") + hipGetErrorString(e); }
+                ++issued;
+            }
+            cv.notify_all();
+        }
+    }
+    void push(void *dst, const void *src, size_t bytes, hipStream_t st) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            q.push_back(Job{dst, src, bytes, st});
+            ++pushed;
+        }
+        if (!th.joinable()) th = std::thread([this] { run(); });
+        cv.notify_all();
+    }
+    void wait_issued(long count) {               // until the first `count` jobs have been issued
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return issued >= count; });
+    }
+    int finish() {                               // every job issued, the thread gone; the streams are the caller's to drain
+        if (th.joinable()) {
+            wait_issued(pushed);
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            th.join();
+        }
+        return rc == PCX_OK ? PCX_OK : fail(rc, "%s", err.c_str());
+    }
+    ~Downloader() { (void)finish(); }
 };
 
 // ---------------------------------------------------------------------------------
@@ -1589,50 +1657,47 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
     const int64_t chunk = piped ? piece : kChunkPoints;
     if (piped && !h->stream2)
         HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    // Copies from/to pageable memory block the host until their stream reaches them, so the
-    // result copy of chunk i-1 is issued only after chunk i's upload and launch are queued.
-    int slot = 0;
-    int64_t prev_start = -1;
-    long prev_cnt = 0;
-    auto download = [&](int sl, int64_t start, long cnt) -> int {
-        const bool second = piped && sl == 1;
-        HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, (second ? h->s_out2 : h->s_out).ptr,
-                               (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
+    // The copies queued below read and write the CALLER's arrays: whatever happens, the helper thread is joined and both
+    // streams are drained before this call returns.
+    Downloader dl(h->device);
+    auto pipeline = [&]() -> int {
+        int slot = 0;
+        // a short first piece (one round of workgroups) so that the first kernel starts after 2.6 MB instead of
+        // 10 MB of upload: nothing overlaps the first upload
+        const int64_t first_piece = piped ? (1 << 16) : chunk;
+        long piece_no = 0;
+        for (int64_t start = 0, step = first_piece; start < N; start += step, step = chunk, ++piece_no) {
+            long cnt = (long)std::min<int64_t>(step, N - start);
+            const bool second = piped && slot == 1;
+            hipStream_t st = second ? h->stream2 : h->stream;
+            Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
+            if (piped && piece_no >= 2) dl.wait_issued(piece_no - 1);     // this slot's last download is behind its kernel
+            int rc = sp.reserve((size_t)cnt * d * sizeof(double));
+            if (rc) return rc;
+            rc = so.reserve((size_t)cnt * m * sizeof(double));
+            if (rc) return rc;
+            double *dp = (double *)sp.ptr, *dout = (double *)so.ptr;
+            HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
+            rc = bary_launch_specs(h, derivs, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial);
+            if (rc) return rc;
+            if (!piped) {                             // single slot: download here, drain before its buffers are reused
+                HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                continue;
+            }
+            dl.push(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), st);
+            slot ^= 1;
+        }
         return PCX_OK;
     };
-    // a short first piece (one round of workgroups) so that the first kernel starts after 2.6 MB instead of
-    // 10 MB of upload: nothing overlaps the first upload
-    const int64_t first_piece = piped ? (1 << 16) : chunk;
-    for (int64_t start = 0, step = first_piece; start < N; start += step, step = chunk, slot ^= 1) {
-        long cnt = (long)std::min<int64_t>(step, N - start);
-        const bool second = piped && slot == 1;
-        hipStream_t st = second ? h->stream2 : h->stream;
-        Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
-        int rc = sp.reserve((size_t)cnt * d * sizeof(double));
-        if (rc) return rc;
-        rc = so.reserve((size_t)cnt * m * sizeof(double));
-        if (rc) return rc;
-        double *dp = (double *)sp.ptr, *dout = (double *)so.ptr;
-        HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
-        rc = bary_launch_specs(h, derivs, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial);
-        if (rc) return rc;
-        if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
-        if (!piped) {                             // single slot: drain before its buffers are reused
-            if ((rc = download(slot, start, cnt))) return rc;
-            HIP_TRY(hipStreamSynchronize(st));
-            prev_start = -1;
-            slot ^= 1;                             // stay on slot 0
-            continue;
-        }
-        prev_start = start;
-        prev_cnt = cnt;
-    }
-    if (prev_start >= 0) {
-        int rc = download(slot ^ 1, prev_start, prev_cnt);
-        if (rc) return rc;
-    }
-    HIP_TRY(hipStreamSynchronize(h->stream));
-    if (h->stream2) HIP_TRY(hipStreamSynchronize(h->stream2));
+    const int rc_pipe = pipeline();
+    const int rc_dl = dl.finish();
+    const hipError_t e1 = hipStreamSynchronize(h->stream);
+    const hipError_t e2 = h->stream2 ? hipStreamSynchronize(h->stream2) : hipSuccess;
+    if (rc_pipe) return rc_pipe;
+    if (rc_dl) return rc_dl;
+    HIP_TRY(e1);
+    HIP_TRY(e2);
     return PCX_OK;
 }
 
@@ -2917,56 +2982,46 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
     }
     // The path is transfer-bound (48 .. 88 bytes per point against ~0.1 ns of kernel): pieces of 2^20 points alternate
     // between two staging slots on two streams, so the upload of piece i+1 runs while piece i is evaluated and piece
-    // i-1 is downloaded (both PCIe directions busy).  From page-locked caller memory (pcx_host_register, or the `pin`
+    // i-1 is downloaded (both PCIe directions busy; the downloads are issued by a helper thread, see Downloader).  From page-locked caller memory (pcx_host_register, or the `pin`
     // flag of pcx_tt_group_eval_batch) the copies are asynchronous DMA; from pageable memory the driver stages them.
     const int64_t kTTPipePoints = 1 << 20;
     const bool piped = N >= 2 * kTTPipePoints;
     const int64_t chunk = piped ? kTTPipePoints : kChunkPoints;
     if (piped && !h->stream2) HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
-    // the copies queued below read and write the CALLER's arrays: whatever happens, both streams are drained before
-    // this call returns (an early error return must not leave a download in flight behind it)
+    // the copies queued below read and write the CALLER's arrays: whatever happens, the helper thread (Downloader) is
+    // joined and both streams are drained before this call returns
+    Downloader dl(h->device);
     auto pipeline = [&]() -> int {
         int slot = 0;
-        int64_t prev_start = -1;
-        long prev_cnt = 0;
-        auto download = [&](int sl, int64_t start, long cnt) -> int {
-            const bool second = piped && sl == 1;
-            HIP_TRY(hipMemcpyAsync(out + start, (second ? h->s_out2 : h->s_out).ptr, (size_t)cnt * sizeof(double),
-                                   hipMemcpyDeviceToHost, second ? h->stream2 : h->stream));
-            return PCX_OK;
-        };
-        for (int64_t start = 0; start < N; start += chunk, slot ^= 1) {
+        long piece_no = 0;
+        for (int64_t start = 0; start < N; start += chunk, ++piece_no) {
             long cnt = (long)std::min<int64_t>(chunk, N - start);
             const bool second = piped && slot == 1;
             hipStream_t st = second ? h->stream2 : h->stream;
             Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
+            if (piped && piece_no >= 2) dl.wait_issued(piece_no - 1);     // this slot's last download is behind its kernel
             int rc = sp.reserve((size_t)cnt * d * sizeof(double));
             if (rc) return rc;
             if ((rc = so.reserve((size_t)cnt * sizeof(double)))) return rc;
             HIP_TRY(hipMemcpyAsync(sp.ptr, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
             rc = tt_launch(h, (const double *)sp.ptr, cnt, (double *)so.ptr, st);
             if (rc) return rc;
-            if (prev_start >= 0 && (rc = download(slot ^ 1, prev_start, prev_cnt))) return rc;
-            if (!piped) {                           // single slot: drain before its buffers are reused
-                if ((rc = download(slot, start, cnt))) return rc;
+            if (!piped) {                           // single slot: download here, drain before its buffers are reused
+                HIP_TRY(hipMemcpyAsync(out + start, so.ptr, (size_t)cnt * sizeof(double), hipMemcpyDeviceToHost, st));
                 HIP_TRY(hipStreamSynchronize(st));
-                prev_start = -1;
-                slot ^= 1;
                 continue;
             }
-            prev_start = start;
-            prev_cnt = cnt;
-        }
-        if (prev_start >= 0) {
-            int rc = download(slot ^ 1, prev_start, prev_cnt);
-            if (rc) return rc;
+            dl.push(out + start, so.ptr, (size_t)cnt * sizeof(double), st);
+            slot ^= 1;
         }
         return PCX_OK;
     };
     const int rc_pipe = pipeline();
+    const int rc_dl = dl.finish();
     const hipError_t e1 = hipStreamSynchronize(h->stream);
     const hipError_t e2 = h->stream2 ? hipStreamSynchronize(h->stream2) : hipSuccess;
     if (rc_pipe) return rc_pipe;
+    if (rc_dl) return rc_dl;
     HIP_TRY(e1);
     HIP_TRY(e2);
     return PCX_OK;
