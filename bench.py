@@ -39,7 +39,8 @@ Also on the JSON line:
                GEMMs; `span0` (no sharing) and `tol_1e-12` (looser probe tolerance) beside it), config 3 (TT-Cross
                build + 10^7-point eval_batch; 200 timed steps after 50 warm-ups: a 0.8 ms step is
                inside the FP64 clock transient for the first ~30 ms), config 5's model at a per-GPU
-               batch (10-D, rank 16, 4x10^6 points) and config 1 (12 x 12, 10^4 points: microseconds
+               batch (10-D, rank 16, 12.5 M points = 10^8 / 8; `full_batch_one_gpu`: all 10^8 x 10 in ONE launch on one
+               GPU) and config 1 (12 x 12, 10^4 points: microseconds
                per call, GPU and CPU) -- same timing discipline, never mixed into `value`.
   cpu_baseline the CPU oracle (C restatement of the reference, OpenMP) on all usable
                host cores, on the per-GPU CPU share (16) and the reference's NumPy shape on
@@ -275,7 +276,8 @@ class TTWork(Workload):
             ranks = [1] + [16] * 9 + [1]
             cores = [rng.standard_normal((ranks[k], 11, ranks[k + 1])) / np.sqrt(ranks[k] * 11) for k in range(10)]
             self.domain = [[-1.0, 1.0]] * 10
-            self.name = "10D synthetic rank-16 ChebyshevTT eval_batch, %s fp64 queries per GPU" % f"{n_points:,}"
+            self.name = "10D synthetic rank-16 ChebyshevTT eval_batch, %s fp64 queries per GPU%s" % (
+                f"{n_points:,}", " (12.5 M = 10^8 / 8: config 5's per-GPU share)" if n_points == 12_500_000 else "")
             self.flop_per_eval, self.bytes_per_eval = 49920.0, 88.0
             self.kernel = "k_tt_eval_mfma<4,1,4>"
         self.d = len(cores)
@@ -341,17 +343,23 @@ def make_workload(lib_mod, name, n_points):
     if name == "greeks5d":
         return Bary5D(lib_mod, n_points or 1_000_000, GREEK_SPECS, "greeks5d")
     if name in ("tt5d", "tt10d"):
-        return TTWork(lib_mod, n_points or (10_000_000 if name == "tt5d" else 4_000_000), name)
+        # config 3: 10^7 points; config 5: 10^8 points over 8 GPUs = 12.5 M per GPU (1 GB of coordinates)
+        return TTWork(lib_mod, n_points or (10_000_000 if name == "tt5d" else 12_500_000), name)
     raise SystemExit(f"unknown workload {name}")
 
 
 # ----------------------------------------------------------------------------------
 # launcher: N child ranks, started before anything touches the GPU
 # ----------------------------------------------------------------------------------
-def launch_children(n: int) -> int:
+def launch_children(n: int, script: str | None = None, argv=None) -> int:
+    """Start n ranks of `script` (this file by default) with the environment a rank expects, forward rank 0's JSON
+    line, stop the others if one fails.  `script` / `argv` exist for the CPU rehearsal of this launcher
+    (tests/test_distributed_cpu.py runs a stand-in rank script through it with 8 ranks)."""
     from pychebyshev_amd import _build
-    if _build.needs_build():                 # hipcc only; no GPU call
+    if script is None and _build.needs_build():                 # hipcc only; no GPU call
         _build.build()
+    script = script or os.path.abspath(__file__)
+    argv = sys.argv[1:] if argv is None else list(argv)
     base = "/dev/shm" if os.path.isdir("/dev/shm") else None
     rdzv = tempfile.mkdtemp(prefix="pcx_rdzv_", dir=base)
     procs = []
@@ -360,7 +368,7 @@ def launch_children(n: int) -> int:
             env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                        PCX_RDZV_DIR=rdzv, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
             env.setdefault("OMP_NUM_THREADS", "2")
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+            procs.append(subprocess.Popen([sys.executable, script] + argv, env=env,
                                           stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno()))
         out0 = b""
         rc = 0
@@ -474,6 +482,20 @@ def run_rank(args) -> int:
     def chk(rc):
         _lib.check(rc, lib)
 
+    def rank_record():
+        """What this rank ran on: answers "did RCCL see N ranks on N distinct GPUs" from the line alone."""
+        import socket
+        rec = {"rank": rank, "local_rank": local_rank, "device": dev, "pid": os.getpid(), "host": socket.gethostname()[:24]}
+        buf = ctypes.create_string_buffer(64)
+        if lib.pcx_device_pci_bus_id(dev, buf, 64) == 0:
+            rec["pci_bus_id"] = buf.value.decode()
+        if comm is not None:
+            r_, w_, d_, v_ = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_int32(0)
+            if lib.pcx_comm_info(comm.handle, ctypes.byref(r_), ctypes.byref(w_), ctypes.byref(d_), ctypes.byref(v_)) == 0:
+                rec.update({"comm_rank": int(r_.value), "comm_world": int(w_.value), "comm_device": int(d_.value),
+                            "rccl_version": int(v_.value)})
+        return rec
+
     def dev_sync():
         chk(lib.pcx_device_synchronize(dev))
 
@@ -504,20 +526,31 @@ def run_rank(args) -> int:
     chk(lib.pcx_stream_create(dev, ctypes.byref(copy_stream)))
     side_stream = comm.stream() if comm is not None else copy_stream
 
+    def block_crc(arr):
+        import zlib
+        return float(zlib.crc32(np.ascontiguousarray(arr).view(np.uint8)))
+
     def measure(wl, steps, warmup, mode):
         """W untimed + K timed steps of one workload, batch resident in HBM beforehand.
         mode: "none" (kernel only), "rccl" (gather of all blocks on rank 0's GPU each step),
         "rccl+d2h" (... and rank 0 downloads the gathered result), "d2h" (every rank downloads
-        its block into the shared pinned host array).  Returns a dict; times are max over ranks."""
+        its block into the shared pinned host array), "h2d+d2h" (every step ALSO uploads the rank's points from
+        page-locked host memory first: the whole host-to-host path on every GPU at once).
+        Returns a dict; times are max over ranks."""
         n = wl.points_per_gpu
         n_out = n * wl.evals_per_point
         pts = np.ascontiguousarray(wl.points(rank))
-        d_pts = ctypes.c_void_p()
-        chk(lib.pcx_dev_malloc(dev, pts.nbytes, ctypes.byref(d_pts)))
-        chk(lib.pcx_memcpy_h2d(dev, d_pts, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes))
+        upload = mode == "h2d+d2h"
         # two result buffers: the gather / download of step i (side stream) overlaps the
         # kernel of step i+1, which writes the other buffer
         nbuf = 1 if mode == "none" else 2
+        d_ptss = []
+        for _ in range(nbuf if upload else 1):
+            p = ctypes.c_void_p()
+            chk(lib.pcx_dev_malloc(dev, pts.nbytes, ctypes.byref(p)))
+            chk(lib.pcx_memcpy_h2d(dev, p, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes))
+            d_ptss.append(p)
+        pts_locked = upload and lib.pcx_host_register(dev, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes) == 0
         d_outs = []
         for _ in range(nbuf):
             p = ctypes.c_void_p()
@@ -531,15 +564,24 @@ def run_rank(args) -> int:
                 p = ctypes.c_void_p()
                 chk(lib.pcx_dev_malloc(dev, n_out * world * 8, ctypes.byref(p)))
                 d_full.append(p)
-        if mode in ("d2h", "rccl+d2h"):
+        if mode in ("d2h", "rccl+d2h", "h2d+d2h"):
             shared = SharedResult(group, n_out * world, device=dev, name="bench_" + wl.key)
-        busy = [None] * nbuf          # event: the side stream has finished with this buffer
+        busy = [None] * nbuf          # event: the side stream has finished with this result buffer
+        kdone = [None] * nbuf         # event: the kernel that read this points buffer has finished (uploads only)
         count = [0]
         g_events = []
 
         def step(kev=None):
             slot = count[0] % nbuf
             count[0] += 1
+            d_pts = d_ptss[slot % len(d_ptss)]
+            if upload:
+                if kdone[slot] is not None:
+                    chk(lib.pcx_stream_wait_event(copy_stream, kdone[slot]))   # the points buffer is free again
+                chk(lib.pcx_memcpy_h2d_async(d_pts, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes, copy_stream))
+                up = new_event()
+                chk(lib.pcx_event_record(up, copy_stream))
+                chk(lib.pcx_stream_wait_event(stream, up))
             if busy[slot] is not None:
                 chk(lib.pcx_stream_wait_event(stream, busy[slot]))     # kernel must not overwrite a block in flight
             if kev is not None:
@@ -552,6 +594,7 @@ def run_rank(args) -> int:
             done = kev[1] if kev is not None else new_event()
             if kev is None:
                 chk(lib.pcx_event_record(done, stream))
+            kdone[slot] = done
             chk(lib.pcx_stream_wait_event(side_stream, done))
             g0 = g1 = None
             if kev is not None:
@@ -584,32 +627,45 @@ def run_rank(args) -> int:
         elapsed = group.max(elapsed) if group is not None else elapsed
         kernel_ms = [elapsed_ms(a, b) for a, b in kevs]
         gather_ms = [elapsed_ms(a, b) for a, b in g_events]
-        # sanity: the last step's results are finite (and, gathered, complete)
+        # sanity: the last step's results are finite and, collected, complete -- EVERY rank's block of the gathered /
+        # shared result must equal what that rank itself downloads from its own GPU (CRC-32 of the bytes)
         got = np.empty(n_out)
         chk(lib.pcx_memcpy_d2h(dev, got.ctypes.data_as(ctypes.c_void_p), d_outs[(count[0] - 1) % nbuf], n_out * 8))
         if not np.isfinite(got).all():
             raise SystemExit(f"non-finite results in the benchmark batch ({wl.name})")
-        if rank == 0 and mode in ("rccl", "rccl+d2h"):
-            full = np.empty(n_out * world)
-            chk(lib.pcx_memcpy_d2h(dev, full.ctypes.data_as(ctypes.c_void_p), d_full[(count[0] - 1) % nbuf],
-                                   full.nbytes))
-            if not (np.isfinite(full).all() and np.array_equal(full[:n_out], got)):
-                raise SystemExit("gathered result does not contain rank 0's block")
-        if shared is not None and rank == 0:
-            host = np.array(shared.array, copy=True)
-            if not (np.isfinite(host).all() and np.array_equal(host[:n_out], got)):
-                raise SystemExit("shared host result does not contain rank 0's block")
+        verified = None
+        if group is not None and mode != "none":
+            own = group.gather_floats(block_crc(got))
+            if rank == 0:
+                if mode in ("rccl", "rccl+d2h"):
+                    full = np.empty(n_out * world)
+                    chk(lib.pcx_memcpy_d2h(dev, full.ctypes.data_as(ctypes.c_void_p), d_full[(count[0] - 1) % nbuf],
+                                           full.nbytes))
+                    bad = [r for r in range(world)
+                           if block_crc(full[int(offsets[r]): int(offsets[r] + counts[r])]) != own[r]]
+                    if bad or not np.isfinite(full).all():
+                        raise SystemExit(f"RCCL-gathered result: the blocks of ranks {bad} differ from what those ranks computed")
+                if shared is not None:
+                    host = np.array(shared.array, copy=True)
+                    bad = [r for r in range(world)
+                           if block_crc(host[int(offsets[r]): int(offsets[r] + counts[r])]) != own[r]]
+                    if bad or not np.isfinite(host).all():
+                        raise SystemExit(f"shared host result: the blocks of ranks {bad} differ from what those ranks computed")
+                verified = world
         pinned = shared.pinned if shared is not None else None
         if shared is not None:
             shared.close()
-        for p in [d_pts] + d_outs + d_full:
+        if pts_locked:
+            lib.pcx_host_unregister(pts.ctypes.data_as(ctypes.c_void_p))
+        for p in d_ptss + d_outs + d_full:
             lib.pcx_dev_free(dev, p)
         free_events()
         launches = getattr(wl, "gemms_per_step", wl.evals_per_point)
         avg_launch = float(np.mean(kernel_ms)) / launches
         rec = {"elapsed": elapsed, "kernel_ms": kernel_ms, "avg_launch_ms": avg_launch,
                "avg_launch_ms_per_rank": group.gather_floats(avg_launch) if group is not None else [avg_launch],
-               "side_ms": float(np.mean(gather_ms)) if gather_ms else None, "pinned": pinned}
+               "side_ms": float(np.mean(gather_ms)) if gather_ms else None, "pinned": pinned,
+               "blocks_verified": verified, "points_page_locked": pts_locked if upload else None}
         return rec
 
     def rate(wl, rec, steps):
@@ -621,20 +677,29 @@ def run_rank(args) -> int:
         flop_per_launch = wl.flop_per_eval * n
         achieved = flop_per_launch / avg_launch_s / 1e12
         traffic, source = None, None
+        executed, executed_basis = None, None
         pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc_path):
             try:
                 r = json.load(open(pmc_path)).get(wl.key)
                 if r and r.get("points") == n:
-                    traffic = r["hbm_bytes_per_launch"]
+                    traffic = r.get("hbm_bytes_per_launch")
                     source = f"cached PMC (not collected in this run): {r.get('source')}"
+                    executed, executed_basis = r.get("executed_flop_per_launch"), r.get("executed_basis")
             except Exception:
                 traffic = None
+        lpp = "lpp" in wl.kernel
         pipe = ("FP64 VALU (v_fma_f64, lane per point): the FP64 vector peak equals the FP64 matrix peak on MI355X and the two "
-                "share one pipe, so the same 78.6 TFLOP/s roofline binds") if "lpp" in wl.kernel else "FP64 MFMA (v_mfma_f64_16x16x4_f64)"
-        return {"bound": "mfma", "pipe": pipe, "kernel": wl.kernel, "achieved": achieved,
+                "share one pipe, so the same 78.6 TFLOP/s roofline binds") if lpp else "FP64 MFMA (v_mfma_f64_16x16x4_f64)"
+        # `frac` prices the ALGORITHMIC flop; `executed_frac` the flop the FP64 pipe was actually asked for
+        # (matrix kernels: the MFMA flop counter -- the folded-K GEMM needs 6 % fewer FMAs than the reference's nested
+        # reduction, so it is BELOW frac; vector kernels: every vector instruction as a 64-lane FMA, i.e. issue-slot
+        # occupancy at the nominal clock, ABOVE frac), from the committed PMC profile of the same batch size
+        return {"bound": "valu_f64" if lpp else "mfma", "pipe": pipe, "kernel": wl.kernel, "achieved": achieved,
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                 "frac": achieved / FP64_MFMA_PEAK_TFLOPS,
+                "executed_frac": (executed / avg_launch_s / 1e12 / FP64_MFMA_PEAK_TFLOPS) if executed else None,
+                "executed_flop_per_launch": executed, "executed_basis": executed_basis,
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_hbm_bytes_per_launch": wl.bytes_per_eval * n,
@@ -711,13 +776,20 @@ def run_rank(args) -> int:
         if comm is not None:
             modes += [("rccl", "RCCL gather on rank 0's GPU each step, overlapping the next launch"),
                       ("rccl+d2h", "RCCL gather, then rank 0 downloads the full result to pinned host memory")]
-        modes += [("d2h", "no collective: every rank downloads its block into one pinned shared-memory array")]
+        modes += [("d2h", "no collective: every rank downloads its block into one pinned shared-memory array"),
+                  ("h2d+d2h", "host to host: every rank uploads its points from page-locked memory, evaluates, downloads its "
+                              "block into the shared array -- all ranks on PCIe at once (SURVEY App. D.5 (ii))")]
         for mode, what in modes:
             rec = headline if mode == headline_mode else measure(wl, steps, warmup, mode)
             out[mode] = {"what": what, "value": rate(wl, rec, steps), "ms_per_step": rec["elapsed"] / steps * 1e3,
                          "side_stream_ms_per_step": rec["side_ms"]}
             if rec["pinned"] is not None:
                 out[mode]["host_buffer_pinned"] = rec["pinned"]
+            if rec.get("points_page_locked") is not None:
+                out[mode]["points_page_locked"] = rec["points_page_locked"]
+            if rec.get("blocks_verified") is not None:
+                out[mode]["blocks_verified"] = ("block of every rank (%d) in the collected result = that rank's own download, "
+                                                "CRC-32" % rec["blocks_verified"])
         return out
 
     def config1_companion():
@@ -794,6 +866,16 @@ def run_rank(args) -> int:
         return out
 
     multi = group is not None
+    ranks_on = None
+    if multi:
+        blobs = group.allgather_bytes(json.dumps(rank_record(), separators=(",", ":")).encode()[:480])
+        if rank == 0:
+            ranks_on = []
+            for b_ in blobs:
+                try:
+                    ranks_on.append(json.loads(b_.decode()))
+                except ValueError:
+                    ranks_on.append({"error": "unreadable rank record"})
     headline_mode = "none" if not multi else ("rccl" if comm is not None else "d2h")
     if args.gather != "auto":
         if args.gather in ("rccl", "rccl+d2h") and comm is None:
@@ -943,9 +1025,16 @@ def run_rank(args) -> int:
             line["config"]["build"] = wl.build_info
         if multi:
             line["gather"] = gathers
+            buses = [r_.get("pci_bus_id") for r_ in ranks_on]
             line["comm"] = {"backend": "rccl" if comm is not None else None,
                             "rccl_version": comm.rccl_version if comm is not None else None,
-                            "rccl_error": rccl_error, "torch": "torch" in sys.modules}
+                            "rccl_error": rccl_error, "torch": "torch" in sys.modules,
+                            "world": world,
+                            "rccl_world_seen_by_every_rank": (sorted({r_.get("comm_world") for r_ in ranks_on}) == [world]
+                                                              if comm is not None else None),
+                            "distinct_gpus": len({b_ for b_ in buses if b_}),
+                            "ranks": ranks_on}
+            line["config"]["blocks_verified"] = head.get("blocks_verified")
         line.update(companions)
     if world == 1 and not args.no_cpu_baseline:
         def guarded(what, fn):
@@ -972,6 +1061,8 @@ def run_rank(args) -> int:
             boot_group.close()
         group.close()
     if stuck_init:                            # a thread is still inside librccl: leave without joining it
+        if rank == 0 and boot_group is not None:          # ... and its rendezvous directory is nobody's to close
+            shutil.rmtree(boot_group.directory, ignore_errors=True)
         sys.stderr.flush()
         os._exit(0)
     return 0

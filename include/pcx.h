@@ -54,6 +54,8 @@ int pcx_abi_version(void);
 const char *pcx_last_error(void);
 int pcx_device_count(int *n);
 int pcx_device_info(int device, char *name, int name_len, int *compute_units, int64_t *hbm_bytes);
+/* PCI bus id of the device ("0000:05:00.0"): lets a multi-rank run prove that its ranks sat on distinct GPUs */
+int pcx_device_pci_bus_id(int device, char *buf, int len);
 
 /* Device-memory plumbing for callers that keep query batches resident in HBM
  * (bench.py, multi-GPU drivers).  `stream` arguments are hipStream_t passed as void*. */

@@ -18,9 +18,13 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpcx_hip.so")
 # translation unit -> headers it includes (an object is rebuilt when any of them is newer)
 PCX_H = os.path.join("..", "..", "include", "pcx.h")
+HOST_H = ["pcx_common.h", "pcx_internal.h", PCX_H]
 SOURCES = {
-    "pcx_api.hip": ["pcx_common.h", "bary_kernels.h", "tt_kernels.h", "tt_lpp_kernels.h", "ttcross_kernels.h", "ttsvd_kernels.h",
-                    PCX_H],
+    "pcx_core.hip": HOST_H,
+    "pcx_bary.hip": HOST_H + ["pcx_bary_internal.h", "bary_kernels.h", "gather_kernels.h"],
+    "pcx_spline.hip": HOST_H + ["pcx_bary_internal.h", "gather_kernels.h", "route_kernels.h"],
+    "pcx_tt.hip": HOST_H + ["tt_kernels.h", "tt_lpp_kernels.h", "tt_fd_kernels.h"],
+    "pcx_ttbuild.hip": HOST_H + ["ttcross_kernels.h", "ttsvd_kernels.h"],
     "pcx_comm.hip": [PCX_H],
 }
 OBJ_DIR = os.path.join(HERE, "_obj")
@@ -101,17 +105,36 @@ def build(force: bool = False, verbose: bool = False) -> str:
         return LIB
     hipcc = hipcc_path()
     os.makedirs(OBJ_DIR, exist_ok=True)
-    objs = []
+    digest_at_start = _source_digest()
+    objs, stale = [], []
     for src in SOURCES:
         obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or not os.path.exists(obj) or _read(obj + ".stamp") != _tu_digest(src):
-            _run([hipcc, f"--offload-arch={ARCH}", "-c"] + FLAGS + ["-o", obj, os.path.join(CSRC, src)], verbose)
-            with open(obj + ".stamp", "w") as fh:
-                fh.write(_tu_digest(src) + "\n")
+            stale.append((src, obj))
+
+    def compile_one(item):
+        src, obj = item
+        digest = _tu_digest(src)         # of what the compiler is about to read (an edit during the build stays stale)
+        _run([hipcc, f"--offload-arch={ARCH}", "-c"] + FLAGS + ["-o", obj, os.path.join(CSRC, src)], verbose)
+        with open(obj + ".stamp", "w") as fh:
+            fh.write(digest + "\n")
+
+    # the translation units are independent: compile the stale ones side by side (PCX_BUILD_JOBS, default 4)
+    jobs = max(1, min(len(stale), int(os.environ.get("PCX_BUILD_JOBS", "4"))))
+    if jobs > 1:
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(jobs) as pool:
+            list(pool.map(compile_one, stale))
+    else:
+        for item in stale:
+            compile_one(item)
+    for stale_obj in os.listdir(OBJ_DIR):                   # objects of translation units that no longer exist
+        if stale_obj.endswith(".o") and os.path.join(OBJ_DIR, stale_obj) not in objs:
+            os.remove(os.path.join(OBJ_DIR, stale_obj))
     _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"], verbose)
     with open(STAMP, "w") as fh:
-        fh.write(_source_digest() + "\n")
+        fh.write(digest_at_start + "\n")
     return LIB
 
 

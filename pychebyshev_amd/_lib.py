@@ -50,6 +50,7 @@ SIGNATURES = {
     "pcx_last_error": (ctypes.c_char_p, []),
     "pcx_device_count": (_I, [ctypes.POINTER(_I)]),
     "pcx_device_info": (_I, [_I, ctypes.c_char_p, _I, ctypes.POINTER(_I), c_i64p]),
+    "pcx_device_pci_bus_id": (_I, [_I, ctypes.c_char_p, _I]),
     "pcx_dev_malloc": (_I, [_I, _Z, c_vpp]),
     "pcx_dev_free": (_I, [_I, _V]),
     "pcx_pointer_device": (_I, [_V, ctypes.POINTER(_I)]),
@@ -121,6 +122,7 @@ SIGNATURES = {
 }
 
 _LIB = None
+_WARNED_FANOUT = False
 
 
 def load(path: str | None = None):
@@ -193,6 +195,16 @@ def fanout_devices():
     such as "0,1,2,3"); ``None`` when unset: one device per process (``default_device``)."""
     v = os.environ.get("PCX_DEVICES", "").strip()
     if not v:
+        return None
+    # one process per GPU (torchrun / bench.py ranks): every rank keeps ITS device -- a fan-out list inherited through
+    # the environment would put every rank's primary handle on devices[0] and replicate the model on all of them
+    if int(os.environ.get("WORLD_SIZE", "1") or 1) > 1 or os.environ.get("LOCAL_RANK", "").strip() != "":
+        global _WARNED_FANOUT
+        if not _WARNED_FANOUT:
+            _WARNED_FANOUT = True
+            import sys
+            sys.stderr.write("pychebyshev_amd: PCX_DEVICES ignored in a multi-rank launch (WORLD_SIZE / LOCAL_RANK set): "
+                             "pass to_device(devices=...) explicitly to fan out from a rank\n")
         return None
     if v.lower() == "all":
         return list(range(max(1, device_count())))

@@ -24,7 +24,12 @@
 
 #include "../../include/pcx.h"
 
-int pcx_fail_v(int code, const char *fmt, va_list ap);   // pcx_api.hip (thread-local message)
+int pcx_fail_v(int code, const char *fmt, va_list ap);   // pcx_core.hip (thread-local message)
+// pcx_core.hip: no C++ exception crosses the C ABI (see pcx_internal.h)
+int pcx_guard_caught(const char *fn) noexcept;
+void pcx_fault_inject(const char *fn);
+#define PCX_API_BEGIN try { pcx_fault_inject(__func__);
+#define PCX_API_END } catch (...) { return pcx_guard_caught(__func__); }
 
 static int fail(int code, const char *fmt, ...) {
     va_list ap;
@@ -121,6 +126,7 @@ struct pcx_comm {
 };
 
 extern "C" int pcx_comm_unique_id(void *id_out) {
+    PCX_API_BEGIN
     if (!id_out) return fail(PCX_ERR_INVALID, "id_out is NULL");
     static_assert(sizeof(ncclUniqueId) == PCX_COMM_ID_BYTES, "RCCL unique id size");
     int rc = rccl_ready();
@@ -129,9 +135,11 @@ extern "C" int pcx_comm_unique_id(void *id_out) {
     NCCL_TRY(g_rccl.GetUniqueId(&id));
     memcpy(id_out, &id, sizeof(id));
     return PCX_OK;
+    PCX_API_END
 }
 
 extern "C" int pcx_comm_create(int device, int rank, int world, const void *id, pcx_comm **out) {
+    PCX_API_BEGIN
     if (!out || !id) return fail(PCX_ERR_INVALID, "NULL argument");
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world)
@@ -163,9 +171,11 @@ extern "C" int pcx_comm_create(int device, int rank, int world, const void *id, 
     }
     *out = c;
     return PCX_OK;
+    PCX_API_END
 }
 
 extern "C" int pcx_comm_destroy(pcx_comm *c) {
+    PCX_API_BEGIN
     if (!c) return PCX_OK;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
@@ -174,10 +184,12 @@ extern "C" int pcx_comm_destroy(pcx_comm *c) {
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return PCX_OK;
+    PCX_API_END
 }
 
 extern "C" int pcx_comm_info(pcx_comm *c, int32_t *rank, int32_t *world, int32_t *device,
                              int32_t *rccl_version) {
+    PCX_API_BEGIN
     if (!c) return fail(PCX_ERR_INVALID, "comm is NULL");
     if (rank) *rank = c->rank;
     if (world) *world = c->world;
@@ -188,17 +200,21 @@ extern "C" int pcx_comm_info(pcx_comm *c, int32_t *rank, int32_t *world, int32_t
         *rccl_version = v;
     }
     return PCX_OK;
+    PCX_API_END
 }
 
 extern "C" int pcx_comm_stream(pcx_comm *c, void **stream) {
+    PCX_API_BEGIN
     if (!c || !stream) return fail(PCX_ERR_INVALID, "NULL argument");
     *stream = (void *)c->stream;
     return PCX_OK;
+    PCX_API_END
 }
 
 extern "C" int pcx_comm_gatherv_dev(pcx_comm *c, const double *d_send, double *d_recv,
                                     const int64_t *counts, const int64_t *offsets, int root,
                                     void *stream) {
+    PCX_API_BEGIN
     if (!c || !counts || !offsets) return fail(PCX_ERR_INVALID, "NULL argument");
     if (root < 0 || root >= c->world) return fail(PCX_ERR_INVALID, "root %d outside [0, %d)", root, c->world);
     for (int r = 0; r < c->world; ++r)
@@ -234,9 +250,11 @@ extern "C" int pcx_comm_gatherv_dev(pcx_comm *c, const double *d_send, double *d
         NCCL_TRY(g_rccl.GroupEnd());
     }
     return PCX_OK;
+    PCX_API_END
 }
 
 extern "C" int pcx_comm_allreduce_max(pcx_comm *c, double *value) {
+    PCX_API_BEGIN
     if (!c || !value) return fail(PCX_ERR_INVALID, "NULL argument");
     HIP_TRY(hipSetDevice(c->device));
     HIP_TRY(hipMemcpyAsync(c->d_scratch, value, sizeof(double), hipMemcpyHostToDevice, c->stream));
@@ -244,9 +262,12 @@ extern "C" int pcx_comm_allreduce_max(pcx_comm *c, double *value) {
     HIP_TRY(hipMemcpyAsync(value, c->d_scratch + 1, sizeof(double), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return PCX_OK;
+    PCX_API_END
 }
 
 extern "C" int pcx_comm_barrier(pcx_comm *c) {
+    PCX_API_BEGIN
     double v = 0.0;
     return pcx_comm_allreduce_max(c, &v);
+    PCX_API_END
 }

@@ -53,6 +53,23 @@ struct BaryG0 {
     int col[PCX_G0_MAX];     // output column of member s
 };
 
+// "Plain" (C-order) tensors carry PCX_PLAIN_PAD zeroed doubles behind their end: the lane-per-point kernels read a
+// row with a fixed-width run of scalar loads that may reach past the last row.
+#define PCX_PLAIN_PAD 64
+
+// lane-per-point kernels (k_bary_small, k_bary_sq): power-of-two coordinate scales of the weight products
+struct BarySmallScale {
+    double s[4];            // 2^e per dimension (d <= 4)
+};
+
+// one piece of a piecewise interpolant as the all-pieces-in-one-launch kernels read it (device table, scalar loads)
+struct SplinePieceModel {
+    const double *snodes, *nodes, *wts;
+    const double *T;                    // the piece's tensor (m == 1) ...
+    const double *const *T_tab;         // ... or its device table of m tensors (NULL when m == 1)
+    BarySmallScale sc;
+};
+
 // ---- tensor-train kernel parameters ---------------------------------------------
 struct TTDims {
     int d;

@@ -291,3 +291,28 @@ __global__ void k_value_to_coeff_core(const double *__restrict__ v, double *__re
     if (k == 0) s *= 0.5;
     out[idx] = s;
 }
+
+// _eval_tt (tensor_train.py:223-228) batched over integer grid index tuples: one thread
+// per tuple walks the chain of VALUE cores (cores in their natural (r, n, r') layout).
+__global__ void k_tt_grid_eval(int d, const int *__restrict__ n, const int *__restrict__ ranks,
+                               const long *__restrict__ coff, const double *__restrict__ cores,
+                               const int *__restrict__ idx, int count, double *__restrict__ out,
+                               double *__restrict__ work, int rmax) {
+    int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= count) return;
+    double *v = work + (size_t)p * 2 * rmax;
+    double *v2 = v + rmax;
+    v[0] = 1.0;
+    for (int k = 0; k < d; ++k) {
+        int rl = ranks[k], rr = ranks[k + 1], nk = n[k];
+        int i = idx[(long)p * d + k];
+        const double *G = cores + coff[k];
+        for (int b = 0; b < rr; ++b) {
+            double s = 0.0;
+            for (int a = 0; a < rl; ++a) s = __builtin_fma(v[a], G[((long)a * nk + i) * rr + b], s);
+            v2[b] = s;
+        }
+        double *sw = v; v = v2; v2 = sw;
+    }
+    out[p] = v[0];
+}

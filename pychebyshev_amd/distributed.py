@@ -50,9 +50,21 @@ def shard_table(n_rows: int, world_size: int, width: int = 1):
 # host rendezvous
 # --------------------------------------------------------------------------------------
 _MAGIC = 0x5043584752503031          # "PCXGRP01"
-_HDR = 64                            # magic, world, created_ns
+_HDR = 64                            # magic, world, created_ns, launch nonce
 _SLOT = 512                          # gen (i64), blob length (i64), blob (<= 496 bytes)
 _BLOB_MAX = _SLOT - 16
+
+
+class _StaleRendezvous(TimeoutError):
+    """The mapped rendezvous file was replaced before this rank's first barrier passed."""
+
+
+def _launch_nonce() -> int:
+    """The same number on every rank of one launch, different between launches that share a directory."""
+    import zlib
+    key = "%s|%d|%s|%s" % (os.environ.get("PCX_RDZV_NONCE", ""), os.getppid(), os.environ.get("MASTER_PORT", ""),
+                           os.environ.get("TORCHELASTIC_RESTART_COUNT", ""))
+    return zlib.crc32(key.encode()) + 1
 
 
 class HostGroup:
@@ -68,7 +80,11 @@ class HostGroup:
         self.directory = directory
         self.path = os.path.join(directory, "group.bin")
         self._gen = 0
-        size = _HDR + world * _SLOT
+        self._mm = None
+        self._size = _HDR + world * _SLOT
+        # every rank of ONE launch computes the same nonce (same launcher process, same master port / restart count,
+        # or an explicit PCX_RDZV_NONCE): a file left in the same directory by another launch does not match it
+        self._nonce = _launch_nonce()
         if rank == 0:
             os.makedirs(directory, exist_ok=True)
             try:
@@ -77,10 +93,28 @@ class HostGroup:
                 pass
             tmp = self.path + f".{os.getpid()}.tmp"
             with open(tmp, "wb") as f:
-                f.write(struct.pack("<qqq", _MAGIC, world, time.time_ns()).ljust(_HDR, b"\0"))
+                f.write(struct.pack("<qqqq", _MAGIC, world, time.time_ns(), self._nonce).ljust(_HDR, b"\0"))
                 f.write(b"\0" * (world * _SLOT))
             os.rename(tmp, self.path)                    # appears complete or not at all
         deadline = time.monotonic() + timeout
+        # Attach, then pass the first barrier.  A rank that started before rank 0 may have mapped the (still fresh)
+        # file of a crashed launch whose slot for this rank was never written: rank 0 of THIS launch then replaces the
+        # file under it.  That is noticed inside the first barrier (the path names another inode): the mapping is
+        # dropped and the rank goes back to polling for rank 0's new file, until the deadline.
+        while True:
+            self._attach(deadline)
+            self._attached = False       # until the handshake passes, keep checking that the path still names this file
+            try:
+                self._hello()
+            except _StaleRendezvous:
+                self._drop_mapping()
+                self._gen = 0
+                continue
+            self._attached = True
+            break
+
+    def _attach(self, deadline: float):
+        rank, world, size = self.rank, self.world, self._size
         self._ino = None
         while True:
             try:
@@ -88,14 +122,15 @@ class HostGroup:
                 try:
                     st = os.fstat(fd)
                     if st.st_size == size:
-                        head = os.pread(fd, 24, 0)
-                        magic, w, created = struct.unpack("<qqq", head)
+                        head = os.pread(fd, 32, 0)
+                        magic, w, created, nonce = struct.unpack("<qqqq", head)
                         fresh = abs(time.time_ns() - created) < 900e9
-                        # A file left by a crashed run with the same key is recognised by this rank's own slot:
-                        # only its owner ever writes a slot, so in the file of THIS launch its generation is
+                        # A file left by a crashed run with the same key is recognised by its nonce, or by this rank's
+                        # own slot: only its owner ever writes a slot, so in the file of THIS launch its generation is
                         # still 0 (rank 0 unlinks and recreates the file; wait for the new one).
                         (own_gen,) = struct.unpack("<q", os.pread(fd, 8, _HDR + rank * _SLOT))
-                        if magic == _MAGIC and w == world and fresh and own_gen == 0 and self._same_file(st):
+                        if (magic == _MAGIC and w == world and fresh and nonce == self._nonce and own_gen == 0
+                                and self._same_file(st)):
                             self._mm = mmap.mmap(fd, size)
                             self._ino = (st.st_dev, st.st_ino)
                             break
@@ -108,9 +143,40 @@ class HostGroup:
             time.sleep(0.002)
         self._gens = np.frombuffer(self._mm, dtype=np.int64, count=world * (_SLOT // 8),
                                    offset=_HDR)[:: _SLOT // 8]
-        self._attached = False           # until the first barrier passes, keep checking that the path still names this file
-        self.barrier()
-        self._attached = True
+
+    def _hello(self):
+        """Handshake behind every attach: each rank puts a random token into its slot, rank 0 answers with a digest of
+        all of them, every rank checks the digest.  Generation counters alone cannot tell a live file from the one a
+        crashed launch left behind -- its dead ranks sit at high generations and every barrier against them passes at
+        once; a dead rank 0 cannot have signed THIS rank's token."""
+        import hashlib
+        token = os.urandom(8)
+        off = self._slot(self.rank)
+        self._mm[off + 8: off + 16] = struct.pack("<q", 8)
+        self._mm[off + 16: off + 24] = token
+        self.barrier()                                   # every token is in place
+
+        def tokens():
+            return b"".join(bytes(self._mm[self._slot(r) + 16: self._slot(r) + 24]) for r in range(self.world))
+
+        if self.rank == 0:
+            self._mm[off + 24: off + 56] = hashlib.sha256(tokens()).digest()
+            self._mm[off + 8: off + 16] = struct.pack("<q", 40)
+        self.barrier()                                   # rank 0 has signed
+        o0 = self._slot(0)
+        signed = bytes(self._mm[o0 + 24: o0 + 56])
+        if signed != hashlib.sha256(tokens()).digest() or bytes(self._mm[off + 16: off + 24]) != token:
+            raise _StaleRendezvous(f"rank {self.rank}: {self.path} was not signed by rank 0 of this launch")
+        self.barrier()                                   # everyone has checked: the slots may be reused
+
+    def _drop_mapping(self):
+        self._gens = None
+        if self._mm is not None:
+            try:
+                self._mm.close()
+            except BufferError:
+                pass
+        self._mm = None
 
     def _same_file(self, st) -> bool:
         """The path still names the file behind `st` (rank 0 replaces a stale file by unlink + rename)."""
@@ -153,15 +219,15 @@ class HostGroup:
             spins += 1
             if spins > 200:
                 time.sleep(0.0002)
-                if not self._attached and spins % 1000 == 0:
+                if not self._attached and spins % 50 == 0:
                     now = None
                     try:
                         now = os.stat(self.path)
                     except FileNotFoundError:
                         pass
                     if now is None or (now.st_dev, now.st_ino) != self._ino:
-                        raise TimeoutError(f"rank {self.rank}: attached to a stale rendezvous file {self.path} "
-                                           "(replaced by rank 0 of this launch); start the ranks again")
+                        # rank 0 of this launch replaced the file this rank had mapped: attach again (__init__)
+                        raise _StaleRendezvous(f"rank {self.rank}: attached to a stale rendezvous file {self.path}")
                 if time.monotonic() > deadline:
                     late = [r for r in range(self.world) if int(self._gens[r]) < gen]
                     raise TimeoutError(f"rank {self.rank}: ranks {late} did not reach barrier {gen}")

@@ -46,23 +46,46 @@ def parity(y, ref, floor=0.0):
     return e_norm, e_point
 
 
+# every assert_parity call of the session: (what, E_norm, E_point, point_tol) -- written to
+# gpurun_out/parity_pointwise.json at the end so that the worst case per derivative order can be quoted
+_PARITY_LOG = []
+
+
 def assert_parity(y, ref, tol=1e-12, what="", point_tol=None, floor=0.0):
     """Normwise bound `tol` (the north_star's 1e-12 for fp64 barycentric) plus a pointwise
-    bound on the significant points.  For derivative specs pass point_tol=1e-11: two valid
-    fp64 summation orders of a D^2-transformed tensor already differ by ~2e-12 pointwise
-    (SURVEY.md App. B), so only the normwise figure can be held at 1e-12 there."""
+    bound on the significant points (|ref| >= 1e-3 max|ref|).  Derivative
+    specs pass spec_point_tol(spec): a finite bound per total order."""
     e_norm, e_point = parity(y, ref, floor)
     point_tol = tol if point_tol is None else point_tol
+    assert np.isfinite(point_tol), f"{what}: every parity check carries a finite pointwise bound"
+    _PARITY_LOG.append({"what": what, "e_norm": e_norm, "e_point": e_point, "point_tol": float(point_tol)})
     assert e_norm <= tol and e_point <= point_tol, \
         f"{what}: E_norm={e_norm:.3e} (tol {tol}) E_point={e_point:.3e} (tol {point_tol})"
 
 
 def spec_point_tol(spec):
-    """Pointwise bound: 1e-12 for value specs.  Derivative specs are held to the normwise
-    1e-12 only: the differentiation matrices amplify rounding by ~n^2 per order, so two
-    equally valid fp64 evaluation orders (the reference's own dgemm vs dgemv siblings
-    included) differ pointwise by 1e-11..1e-10 at n = 12..20 while agreeing normwise."""
-    return 1e-12 if not any(int(v) for v in spec) else float("inf")
+    """Pointwise bound on |ref| >= 1e-3 max|ref| by total derivative order (SURVEY.md 8(d) asks for
+    the pointwise check on every derivative spec): 1e-12 for values, 1e-11 for first derivatives,
+    1e-10 for second derivatives and mixed partials, 1e-9 above.  The differentiation matrices amplify
+    rounding by ~n^2 per order, so two equally valid fp64 evaluation orders differ pointwise by that
+    much while agreeing normwise to 1e-12 (App. B: gamma 2e-12 pointwise, vanna 6e-11 where it
+    crosses zero); a sign or indexing error confined to small-magnitude rows is O(1) pointwise and is
+    caught by any of these bounds.  Measured worst cases: DESIGN.md section 5."""
+    order = sum(abs(int(v)) for v in spec)
+    return 1e-12 * 10.0 ** min(order, 3)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _PARITY_LOG:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_pointwise.json"), "w") as fh:
+            json.dump(_PARITY_LOG, fh, indent=0)
+    except OSError:
+        pass
 
 
 @pytest.fixture(scope="session")

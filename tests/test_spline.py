@@ -135,7 +135,7 @@ def test_spline_large_batch_and_empty_pieces(oracle_mod):
     assert_parity(y[sub], ref, 1e-12, "1M spline subset")
     d1 = sp.eval_batch(pts[sub], [1, 0, 0])
     assert_parity(d1, oracle_mod.spline_eval_batch(models, sp.knots, sp._shape, pts[sub], [1, 0, 0]), 1e-12,
-                  "1M spline subset delta", float("inf"))
+                  "1M spline subset delta", spec_point_tol([1, 0, 0]))
 
 
 @pytest.mark.gpu
@@ -160,7 +160,7 @@ def test_spline_near_node_points_on_the_one_launch_path(oracle_mod):
         ref = oracle_mod.spline_eval_batch(models, sp.knots, sp._shape, pts, s)
         got = sp.eval_batch(pts, s)
         assert np.isfinite(got).all()
-        assert_parity(got, ref, 1e-12, f"spline near-node {s}", float("inf"))
+        assert_parity(got, ref, 1e-12, f"spline near-node {s}", spec_point_tol(s))
 
 
 @pytest.mark.gpu
@@ -284,7 +284,7 @@ def test_spline_with_equal_trailing_node_counts_runs_on_the_sq_kernel(monkeypatc
     sub = rng.choice(len(pts), 5000, replace=False)
     for j, sp_ in enumerate(specs):
         ref = oracle_mod.spline_eval_batch(models, sp.knots, sp._shape, pts[sub], sp_)
-        assert_parity(fused[1][sub, j], ref, 1e-12, f"sq spline {sp_}", float("inf"))
+        assert_parity(fused[1][sub, j], ref, 1e-12, f"sq spline {sp_}", spec_point_tol(sp_))
     monkeypatch.setenv("PCX_SPLINE_FUSED", "0")
     sp.to_device(0)                                                        # new handle, created under the override
     per_piece = [sp.eval_batch(pts, specs[0]), sp.eval_multi_batch(pts, specs), sp.eval_batch(some, specs[1]),

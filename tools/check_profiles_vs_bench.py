@@ -41,6 +41,16 @@ def main():
         flag = "" if abs(rel) <= a.tol else "  <-- outside tolerance"
         bad += bool(flag)
         print(f"{wl:10s} {roof['frac']:10.4f} {med:14.4f} {mn:11.4f} {rel:+9.3%}{flag}")
+        # the executed fraction (MFMA / vector-instruction flop the pipe was asked for) the same way
+        ex_line, ex_prof = roof.get("executed_frac"), st.get("executed_frac_of_78.6_TFLOPs_at_median")
+        if ex_line is not None and ex_prof is not None:
+            rel = ex_prof / ex_line - 1.0
+            flag = "" if abs(rel) <= a.tol else "  <-- outside tolerance"
+            bad += bool(flag)
+            print(f"{'  executed':10s} {ex_line:10.4f} {ex_prof:14.4f} {'':11s} {rel:+9.3%}{flag}")
+        elif ex_line is None:
+            print(f"{'  executed':10s}   (no roofline.executed_frac on the line)")
+            bad += 1
     return 1 if bad else 0
 
 

@@ -4,7 +4,7 @@
 default for large pageable batches (it is not: +16 % for TT, +80 % for 12 x 12 at 2^24 points, nothing below 2^19).
 
 Round 3: one run of this sweep ended in a GPU memory access fault in its 2^19 row; tools/soak.py --pin attributed it to the
-two-handle path with the caller's arrays registered for the call; fixed in pcx_api.hip (fanout_arrays_locked).
+two-handle path with the caller's arrays registered for the call; fixed in the library (fanout_arrays_locked, now csrc/pcx_internal.h).
 """
 import numpy as np, sys, time
 sys.path.insert(0,'/root/repo'); sys.path.insert(0,'/root/repo/tests/golden'); sys.path.insert(0,'/root/repo/tools')

@@ -129,6 +129,31 @@ def main():
             summary["sq_mix"] = {k: v[0] for k, v in c.items()}
             if "SQ_INSTS_VALU" in c and a.points:
                 summary["valu_instructions_per_64_points"] = c["SQ_INSTS_VALU"][0] / (a.points / 64.0)
+    # EXECUTED flop per launch (next to the algorithmic count of the roofline): what the FP64 pipe was asked to do.
+    # Matrix kernels: the MFMA flop counter.  Vector kernels (no MFMA): every vector instruction counted as one 64-lane
+    # FMA -- an upper bound of the FP64 work issued, i.e. the issue-slot occupancy of the pipe at the nominal clock.
+    mfma_flop = summary.get("mfma_flop_per_launch", 0.0)
+    valu = summary.get("sq_mix", {}).get("SQ_INSTS_VALU")
+    if mfma_flop:
+        summary["executed_flop_per_launch"] = mfma_flop
+        summary["executed_basis"] = "MFMA flop (SQ_INSTS_VALU_MFMA_MOPS_F64 x 512)"
+    elif valu:
+        summary["executed_flop_per_launch"] = valu * 128.0
+        summary["executed_basis"] = ("vector kernel: SQ_INSTS_VALU x 64 lanes x 2 (every vector instruction counted as an FMA: "
+                                     "issue-slot occupancy of the FP64 pipe at the nominal clock)")
+    if "executed_flop_per_launch" in summary:
+        if a.units_per_step:
+            summary["executed_flop_per_launch"] *= a.launches_per_step / a.units_per_step
+        st = summary.get("timed_steps")
+        if st:
+            st["executed_frac_of_78.6_TFLOPs_at_median"] = summary["executed_flop_per_launch"] / (st["median_ns"] * 1e-9) / 78.6e12
+        tpath = os.path.join(out, "pmc_traffic.json")
+        table = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        ent = table.setdefault(a.workload + a.tag, {"points": a.points, "source": f"profiles/{tag}_summary.json"})
+        if ent.get("points") == a.points:
+            ent["executed_flop_per_launch"] = summary["executed_flop_per_launch"]
+            ent["executed_basis"] = summary["executed_basis"]
+        json.dump(table, open(tpath, "w"), indent=1)
     json.dump(summary, open(os.path.join(out, f"{tag}_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 
