@@ -242,6 +242,17 @@ int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double *out);
  * (reference entry point: tensor_train.py:2217).                                            */
 int pcx_tt_group_eval_batch(pcx_tt *const *handles, int n_handles, const double *pts, int64_t N, double *out, int pin);
 int pcx_tt_eval_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, double *d_out, void *stream);
+/* eval_multi batched (tensor_train.py:2267-2463; the reference evaluates one point per call): value and central
+ * finite-difference derivatives, out[p * m + s] for spec s.  derivs = m x d orders (0, 1 or 2; anything else is
+ * PCX_ERR_INVALID, "... not supported ...") in the USER's dimension order.  The reference's rules in its order of
+ * operations: h = (b - a) 1e-4, the coordinate nudged so that 1.5 h stays inside the domain, 2-point / 3-point rules
+ * nested over the differenced dimensions, the 4-point rule for a mixed (1, 1) partial.  Every stencil point is formed
+ * and evaluated on the device (for lane-per-point models in registers: no stencil batch in HBM); a spec with more
+ * than three differenced dimensions is PCX_ERR_UNSUPPORTED.  Row p equals the per-point stencil evaluated through
+ * pcx_tt_eval_batch bit for bit. */
+int pcx_tt_eval_multi_batch(pcx_tt *h, const double *pts, int64_t N, const int32_t *derivs, int m, double *out);
+int pcx_tt_eval_multi_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, const int32_t *derivs, int m, double *d_out,
+                                void *stream);
 int pcx_tt_stream(pcx_tt *h, void **stream);
 /* Kernel selection: 0 = auto, 1 = direct form on v_mfma_f64_16x16x4 (one GEMM over (node, left
  * rank) per dimension; ranks <= 64), 2 = small-rank "W first" form (ranks <= 12, cores in LDS),

@@ -103,6 +103,8 @@ SIGNATURES = {
     "pcx_tt_destroy": (_I, [_V]),
     "pcx_tt_eval_batch": (_I, [_V, c_f64p, _L, c_f64p]),
     "pcx_tt_eval_batch_dev": (_I, [_V, _V, _L, _V, _V]),
+    "pcx_tt_eval_multi_batch": (_I, [_V, c_f64p, _L, c_i32p, _I, c_f64p]),
+    "pcx_tt_eval_multi_batch_dev": (_I, [_V, _V, _L, c_i32p, _I, _V, _V]),
     "pcx_tt_group_eval_batch": (_I, [c_vpp, _I, c_f64p, _L, c_f64p, _I]),
     "pcx_tt_stream": (_I, [_V, c_vpp]),
     "pcx_tt_set_kernel": (_I, [_V, _I]),

@@ -3,6 +3,7 @@
 #include "pcx_internal.h"
 #include "tt_kernels.h"
 #include "tt_lpp_kernels.h"
+#include "tt_fd_kernels.h"
 
 // ---------------------------------------------------------------------------------
 // tensor-train handle
@@ -44,6 +45,7 @@ struct pcx_tt {
     hipStream_t stream2 = nullptr;   // second staging slot of the host-pointer pipeline (lazy)
     Scratch s_pts2, s_out2;
     Pinned pin;           // zero-copy staging for small host-pointer batches
+    Scratch s_fd_batch, s_fd_vals;   // finite-difference stencil batch and its values (models off the lane-per-point kernel)
 };
 
 extern "C" int pcx_tt_destroy(pcx_tt *h) {
@@ -60,6 +62,7 @@ extern "C" int pcx_tt_destroy(pcx_tt *h) {
     (void)hipFree(h->d_cores);
     h->s_pts.release(); h->s_out.release();
     h->s_pts2.release(); h->s_out2.release();
+    h->s_fd_batch.release(); h->s_fd_vals.release();
     h->pin.release();
     if (h->stream2) { (void)hipStreamSynchronize(h->stream2); (void)hipStreamDestroy(h->stream2); }
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -508,6 +511,174 @@ extern "C" int pcx_tt_eval_batch(pcx_tt *h, const double *pts, int64_t N, double
     const hipError_t e2 = h->stream2 ? hipStreamSynchronize(h->stream2) : hipSuccess;
     if (rc_pipe) return rc_pipe;
     if (rc_dl) return rc_dl;
+    HIP_TRY(e1);
+    HIP_TRY(e2);
+    return PCX_OK;
+    PCX_API_END
+}
+
+// ---------------------------------------------------------------------------------
+// Finite-difference Greeks, batched (reference eval_multi + _fd_*, tensor_train.py:2267-2463; tt_fd_kernels.h)
+// ---------------------------------------------------------------------------------
+// derivs: m x d orders in the USER's dimension order (as ChebyshevTT.eval_multi takes them); the rules run in the
+// storage frame: storage dimension k is user column dims.col[k].
+static int tt_fd_plan(const pcx_tt *h, const int32_t *derivs, int m, std::vector<TTFdSpec> &specs) {
+    const int d = h->dims.d;
+    specs.assign((size_t)m, TTFdSpec{});
+    for (int s = 0; s < m; ++s) {
+        TTFdSpec &sp = specs[(size_t)s];
+        sp.nact = 0;
+        sp.nleaf = 1;
+        for (int k = 0; k < d; ++k) {
+            const int o = derivs ? derivs[(size_t)s * d + h->dims.col[k]] : 0;
+            if (o == 0) continue;
+            if (o != 1 && o != 2) return fail(PCX_ERR_INVALID, "Derivative order %d not supported (use 1 or 2)", o);
+            if (sp.nact == PCX_FD_MAX_ACTIVE)
+                return fail(PCX_ERR_UNSUPPORTED, "more than %d differenced dimensions in one spec: evaluate the stencil on the host",
+                            PCX_FD_MAX_ACTIVE);
+            const int i = sp.nact++;
+            sp.dim[i] = k;
+            sp.order[i] = o;
+            sp.col[i] = h->dims.col[k];
+            sp.lo[i] = h->dims.lo[k];
+            sp.hi[i] = h->dims.hi[k];
+            sp.h[i] = (h->dims.hi[k] - h->dims.lo[k]) * 1e-4;          // tensor_train.py:2324
+            sp.need[i] = sp.h[i] * 1.5;                                 // :2331
+            sp.nleaf *= o + 1;
+        }
+        sp.kind = sp.nact == 0 ? 0 : 1;
+        if (sp.nact == 2 && sp.order[0] == 1 && sp.order[1] == 1) sp.kind = 2;       // :2413-2441, the 4-point mixed partial
+    }
+    return PCX_OK;
+}
+
+static bool tt_runs_lpp(const pcx_tt *h) {
+    return !h->generic && h->lppCap && (h->variant == 4 || (h->variant == 0 && h->lpp_preferred));
+}
+
+// N device-resident points x m specs -> d_out[p * ostride + s]; queued on st, not awaited.  Caller holds h->mu.
+static int tt_fd_launch(pcx_tt *h, const double *d_pts, long N, const std::vector<TTFdSpec> &specs, double *d_out,
+                        long ostride, hipStream_t st) {
+    if (N == 0) return PCX_OK;
+    const int m = (int)specs.size(), d = h->dims.d;
+    for (int s0 = 0; s0 < m; s0 += PCX_FD_PACK) {
+        TTFdPack pack;
+        pack.m = std::min(PCX_FD_PACK, m - s0);
+        pack.slots = 0;
+        for (int s = 0; s < pack.m; ++s) {
+            pack.s[s] = specs[(size_t)(s0 + s)];
+            pack.s[s].slot0 = pack.slots;
+            pack.slots += pack.s[s].nleaf;
+        }
+        if (tt_runs_lpp(h)) {
+            const long blocks = (N + PCX_LPP_WG - 1) / PCX_LPP_WG;
+            if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+            const size_t lds = (size_t)(h->rmax + 3 * PCX_FD_MAX_ACTIVE + 1) * PCX_LPP_WG * sizeof(double);
+#define PCX_FD_GO(RCAP, NJ)                                                                                             \
+            hipLaunchKernelGGL((k_tt_fd_lpp<RCAP, NJ>), dim3((unsigned)blocks), dim3(PCX_LPP_WG), lds, st, h->d_lpp_tab, d,    \
+                               h->rmax, h->d_lpp_img, d_pts, d_out, N, ostride, (long)s0, pack)
+#define PCX_FD_GO_N(RCAP)                                                                                               \
+            switch (h->lpp_nodes) {                                                                                     \
+            case 1: PCX_FD_GO(RCAP, 1); break; case 2: PCX_FD_GO(RCAP, 2); break; case 3: PCX_FD_GO(RCAP, 3); break;    \
+            case 4: PCX_FD_GO(RCAP, 4); break; case 5: PCX_FD_GO(RCAP, 5); break; case 6: PCX_FD_GO(RCAP, 6); break;    \
+            case 7: PCX_FD_GO(RCAP, 7); break; case 8: PCX_FD_GO(RCAP, 8); break; case 9: PCX_FD_GO(RCAP, 9); break;    \
+            case 10: PCX_FD_GO(RCAP, 10); break; case 11: PCX_FD_GO(RCAP, 11); break; case 12: PCX_FD_GO(RCAP, 12); break; \
+            case 13: PCX_FD_GO(RCAP, 13); break; case 14: PCX_FD_GO(RCAP, 14); break; case 15: PCX_FD_GO(RCAP, 15); break; \
+            case 16: PCX_FD_GO(RCAP, 16); break; default: PCX_FD_GO(RCAP, 0); break;                                     \
+            }
+            if (h->lppCap == 8) { PCX_FD_GO_N(8) } else if (h->lppCap == 12) { PCX_FD_GO_N(12) } else { PCX_FD_GO_N(16) }
+#undef PCX_FD_GO_N
+#undef PCX_FD_GO
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
+        // any other evaluation kernel: stencil batch in HBM, in pieces that keep it under ~256 MB
+        const long piece = std::max<long>(4096, std::min<long>(N, (256L << 20) / ((long)pack.slots * d * 8)));
+        int rc = h->s_fd_batch.reserve((size_t)pack.slots * piece * d * sizeof(double));
+        if (rc) return rc;
+        if ((rc = h->s_fd_vals.reserve((size_t)pack.slots * piece * sizeof(double)))) return rc;
+        for (long p0 = 0; p0 < N; p0 += piece) {
+            const long cnt = std::min(piece, N - p0);
+            hipLaunchKernelGGL(k_tt_fd_points, dim3((unsigned)((cnt + 255) / 256), (unsigned)pack.slots), dim3(256), 0, st,
+                               d_pts + (size_t)p0 * d, cnt, d, (double *)h->s_fd_batch.ptr, pack);
+            HIP_TRY(hipGetLastError());
+            rc = tt_launch(h, (const double *)h->s_fd_batch.ptr, (long)pack.slots * cnt, (double *)h->s_fd_vals.ptr, st);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_tt_fd_combine, dim3((unsigned)((cnt + PCX_LPP_WG - 1) / PCX_LPP_WG)), dim3(PCX_LPP_WG), 0, st,
+                               (const double *)h->s_fd_vals.ptr, cnt, d_out + (size_t)p0 * ostride, ostride, (long)s0, pack);
+            HIP_TRY(hipGetLastError());
+        }
+    }
+    return PCX_OK;
+}
+
+extern "C" int pcx_tt_eval_multi_batch_dev(pcx_tt *h, const double *d_pts, int64_t N, const int32_t *derivs, int m,
+                                           double *d_out, void *stream) {
+    PCX_API_BEGIN
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (N > 0 && (!d_pts || !d_out)) return fail(PCX_ERR_INVALID, "NULL device buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::vector<TTFdSpec> specs;
+    int rc = tt_fd_plan(h, derivs, m, specs);
+    if (rc) return rc;
+    // the generic path stages through the handle's scratch: its launches must stay on the handle's own stream
+    hipStream_t st = (stream && tt_runs_lpp(h)) ? (hipStream_t)stream : h->stream;
+    if (stream && st != (hipStream_t)stream) HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    rc = tt_fd_launch(h, d_pts, (long)N, specs, d_out, m, st);
+    if (rc) return rc;
+    if (stream && st != (hipStream_t)stream) HIP_TRY(hipStreamSynchronize(st));
+    return PCX_OK;
+    PCX_API_END
+}
+
+extern "C" int pcx_tt_eval_multi_batch(pcx_tt *h, const double *pts, int64_t N, const int32_t *derivs, int m, double *out) {
+    PCX_API_BEGIN
+    if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
+    if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
+    if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
+    HIP_TRY(hipSetDevice(h->device));
+    std::lock_guard<std::mutex> lk(h->mu);
+    std::vector<TTFdSpec> specs;
+    int rc = tt_fd_plan(h, derivs, m, specs);
+    if (rc) return rc;
+    const int d = h->dims.d;
+    if (N > 0 && (size_t)N * d * sizeof(double) <= kPinnedBytes && (size_t)N * m * sizeof(double) <= kPinnedBytes && h->pin.ready()) {
+        memcpy(h->pin.in, pts, (size_t)N * d * sizeof(double));
+        rc = tt_fd_launch(h, (const double *)h->pin.in, (long)N, specs, (double *)h->pin.out, m, h->stream);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        memcpy(out, h->pin.out, (size_t)N * m * sizeof(double));
+        return PCX_OK;
+    }
+    // pieces of 2^18 points alternate between the two staging slots: the upload of piece i + 1 overlaps the kernel of
+    // piece i (8 m bytes per point come back against 8 d going in; the kernel is (stencil points) chains per point)
+    const int64_t chunk = 1 << 18;
+    const bool two = N > chunk && tt_runs_lpp(h);        // the generic path's scratch is single
+    if (two && !h->stream2) HIP_TRY(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    auto pipeline = [&]() -> int {
+        int slot = 0;
+        for (int64_t start = 0; start < N; start += chunk, slot ^= 1) {
+            const long cnt = (long)std::min<int64_t>(chunk, N - start);
+            const bool second = two && slot == 1;
+            hipStream_t st = second ? h->stream2 : h->stream;
+            Scratch &sp = second ? h->s_pts2 : h->s_pts, &so = second ? h->s_out2 : h->s_out;
+            HIP_TRY(hipStreamSynchronize(st));                       // the slot's previous download has left its buffer
+            int rc2 = sp.reserve((size_t)cnt * d * sizeof(double));
+            if (rc2) return rc2;
+            if ((rc2 = so.reserve((size_t)cnt * m * sizeof(double)))) return rc2;
+            HIP_TRY(hipMemcpyAsync(sp.ptr, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
+            rc2 = tt_fd_launch(h, (const double *)sp.ptr, cnt, specs, (double *)so.ptr, m, st);
+            if (rc2) return rc2;
+            HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, so.ptr, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, st));
+        }
+        return PCX_OK;
+    };
+    const int rc_pipe = pipeline();
+    const hipError_t e1 = hipStreamSynchronize(h->stream);
+    const hipError_t e2 = h->stream2 ? hipStreamSynchronize(h->stream2) : hipSuccess;
+    if (rc_pipe) return rc_pipe;
     HIP_TRY(e1);
     HIP_TRY(e2);
     return PCX_OK;

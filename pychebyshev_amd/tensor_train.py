@@ -592,12 +592,60 @@ class ChebyshevTT(ErgonomicsMixin):
         it = iter(vals)
         return run(lambda p: float(next(it)))         # pass 2: same traversal, real values
 
-    def eval_multi_batch(self, points, derivative_orders, *, chunk: int = 1 << 18) -> np.ndarray:
+    def eval_multi_batch(self, points, derivative_orders, *, chunk: int = 1 << 18):
         """Batched :meth:`eval_multi` (extension; the reference evaluates one point per call): ``(N, d)``
-        points x ``m`` specs -> ``(N, m)``.  The finite-difference rules run on whole columns -- the same
-        record / replay traversal as :meth:`eval_multi` with NumPy columns in place of floats, so row i
-        equals ``eval_multi(points[i], derivative_orders)`` bit for bit -- and all stencil points of a
-        chunk of rows go to the device in one batch."""
+        points x ``m`` specs -> ``(N, m)``.  The finite-difference rules of the reference
+        (``tensor_train.py:2322-2463``) run ON THE DEVICE (``pcx_tt_eval_multi_batch``, ``csrc/tt_fd_kernels.h``):
+        every stencil point is formed from the query row in registers and evaluated by the model's own chain, so
+        row i equals ``eval_multi(points[i], derivative_orders)`` bit for bit and no stencil batch crosses PCIe.
+        A device array in gives a device array out.  Specs with more than three differenced dimensions (27+
+        stencil points) keep the host-side traversal (``_eval_multi_batch_host``)."""
+        self._check_built()
+        d = self.num_dimensions
+        specs_user = [[int(v) for v in s] for s in derivative_orders]
+        for spec in specs_user:
+            if len(spec) != d:
+                raise ValueError(f"each derivative spec needs {d} orders, got {len(spec)}")
+            for o in spec:
+                if o not in (0, 1, 2):
+                    raise ValueError(f"Derivative order {o} not supported (use 1 or 2)")
+        m = len(specs_user)
+        from .device import DeviceArray, as_device_array, check_points, is_device_array
+        on_device = is_device_array(points)
+        if m == 0:
+            n0 = int(points.shape[0]) if hasattr(points, "shape") else len(points)
+            return np.empty((n0, 0))
+        if any(sum(1 for o in spec if o) > 3 for spec in specs_user):
+            if on_device:
+                raise NotImplementedError("specs with more than three differenced dimensions need host arrays")
+            return self._eval_multi_batch_host(points, specs_user, chunk=chunk)
+        t = self._dev()
+        block = _lib.i32(np.asarray(specs_user).reshape(-1))
+        if on_device:
+            dev_pts = as_device_array(points)
+            n = check_points(dev_pts, d, t.device)
+            dout = DeviceArray.empty((n, m), t.device)
+            if n:
+                st = ctypes.c_void_p()
+                _lib.check(t.lib.pcx_tt_stream(t.handle, ctypes.byref(st)), t.lib)
+                _lib.check(t.lib.pcx_tt_eval_multi_batch_dev(t.handle, ctypes.c_void_p(dev_pts.ptr), n, _lib.p_i32(block), m,
+                                                             ctypes.c_void_p(dout.ptr), st), t.lib)
+                _lib.check(t.lib.pcx_stream_synchronize(st), t.lib)
+            return dout
+        pts = _lib.f64(np.asarray(points, dtype=float))
+        if pts.ndim != 2 or pts.shape[1] != d:
+            raise ValueError(f"points must have shape (N, {d}), got {pts.shape}")
+        out = np.empty((pts.shape[0], m))
+        if pts.shape[0]:
+            _lib.check(t.lib.pcx_tt_eval_multi_batch(t.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_i32(block), m,
+                                                     _lib.p_f64(out)), t.lib)
+        return out
+
+    def _eval_multi_batch_host(self, points, derivative_orders, *, chunk: int = 1 << 18) -> np.ndarray:
+        """The finite-difference rules on NumPy columns -- the same record / replay traversal as :meth:`eval_multi`
+        with columns in place of floats; all stencil points of a chunk of rows go to the device in one batch.
+        Kept for specs the device rules do not take (more than three differenced dimensions) and as the
+        row-by-row cross-check of the device path in the tests."""
         self._check_built()
         d = self.num_dimensions
         pts = np.asarray(points, dtype=float)

@@ -307,7 +307,8 @@ def test_tt_fd_rules_replay_on_host():
 
 
 def test_tt_batched_fd_rules_equal_the_per_point_rules():
-    """eval_multi_batch runs the same rules on NumPy columns: row i = eval_multi(points[i]) bit for bit, with
+    """The host-side batched rules (the cross-check of the device path, and what specs with more than three differenced
+    dimensions use) run the same rules on NumPy columns: row i = eval_multi(points[i]) bit for bit, with
     nudged boundary rows, the 4-point mixed rule and a permuted storage order (stand-in evaluator, no device)."""
     cores = [np.ones((1, 4, 1)), np.ones((1, 3, 1)), np.ones((1, 5, 1))]
     dom = [[0.0, 1.0], [0.0, 2.0], [-1.0, 3.0]]
@@ -326,13 +327,15 @@ def test_tt_batched_fd_rules_equal_the_per_point_rules():
         pts[0] = [0.0, 2.0, -1.0]
         pts[1, 2] = 3.0 - 1e-6
         specs = [[0, 0, 0], [1, 0, 0], [0, 2, 0], [1, 0, 1], [0, 1, 1], [1, 2, 0], [2, 0, 2]]
-        got = tt.eval_multi_batch(pts, specs)
+        got = tt._eval_multi_batch_host(pts, specs)
         assert calls == [40 * (1 + 2 + 3 + 4 + 4 + 6 + 9)]            # one device batch for the whole block
         for i in range(40):
             assert np.array_equal(got[i], tt.eval_multi(list(pts[i]), specs)), (order, i)
-        assert np.array_equal(tt.eval_multi_batch(pts, specs, chunk=9), got)
+        assert np.array_equal(tt._eval_multi_batch_host(pts, specs, chunk=9), got)
         with pytest.raises(ValueError, match="not supported"):
-            tt.eval_multi_batch(pts, [[0, 3, 0]])
+            tt._eval_multi_batch_host(pts, [[0, 3, 0]])
+        with pytest.raises(ValueError, match="not supported"):
+            tt.eval_multi_batch(pts, [[0, 3, 0]])                     # validated before anything reaches the device
 
 
 def test_shard_bounds_cover_everything_once():
