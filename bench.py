@@ -671,6 +671,18 @@ def run_rank(args) -> int:
     def rate(wl, rec, steps):
         return float(wl.points_per_gpu) * wl.evals_per_point * world * steps / rec["elapsed"]
 
+    def sustained_of(wl, frac):
+        """the vector-pipe kernel against what a stream of ITS OWN operand pattern sustains with nothing
+        around it (profiles/r04_tt_w4_lab.txt: 88 scalar operands per 97 FP64 instructions through s_load_dwordx16: 0.96 of
+        the nominal instruction rate at 2.37 GHz -- not measured in this run) times its instruction mix (2,280 algorithmic
+        FMAs in 2,469 vector instructions per 64 points)."""
+        if "k_tt_eval_lpp<8,11>" not in wl.kernel:
+            return {}
+        ceiling = 0.96 * 2280.0 / 2469.0
+        return {"sustained": {"stream_frac_of_peak": 0.96, "algorithmic_fma_per_vector_instruction": 2280.0 / 2469.0,
+                              "ceiling_frac": ceiling, "source": "cached: profiles/r04_tt_w4_lab.txt (tools/tt_w4_lab.hip, lpp-like stream)"},
+                "frac_of_sustained": frac / ceiling}
+
     def roofline_of(wl, rec):
         n = wl.points_per_gpu
         avg_launch_s = rec["avg_launch_ms"] / 1e3
@@ -704,7 +716,8 @@ def run_rank(args) -> int:
                 "algorithmic_flop_per_launch": flop_per_launch,
                 "algorithmic_hbm_bytes_per_launch": wl.bytes_per_eval * n,
                 "hbm_frac": wl.bytes_per_eval * n / avg_launch_s / 1e9 / HBM_PEAK_GBS,
-                "traffic": traffic, "traffic_source": source}
+                "traffic": traffic, "traffic_source": source,
+                **sustained_of(wl, achieved / FP64_MFMA_PEAK_TFLOPS)}
 
     def end_to_end(wl, reps=3):
         """Host-pointer entry point on rank 0's batch: pageable NumPy in, NumPy out; then the same call on arrays the

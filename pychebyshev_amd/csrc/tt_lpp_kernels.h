@@ -40,6 +40,9 @@ struct TTLppDim {
 #define PCX_LPP_MAX_RANK 16
 #define PCX_LPP_MAX_NODES 16
 #define PCX_LPP_WG 64
+#ifndef PCX_LPP_MINB8
+#define PCX_LPP_MINB8 8       // ranks <= 8
+#endif
 #ifndef PCX_LPP_MINB12
 #define PCX_LPP_MINB12 6      // ranks 9..12 at <= 80 VGPRs: at 8 (<= 64 VGPRs) the rank-12 body spills (10-D rank 12: 0.55 against 0.65)
 #endif
@@ -115,7 +118,7 @@ __device__ __forceinline__ void tt_lpp_dim(int rl, pcx_lpp_cptr G, int rr, doubl
 // than across the 256 bodies of the two-level switch), 0 = node counts differ: dispatch on both.
 // The coordinate of dimension k + 1 is fetched while dimension k is contracted.
 template <int RCAP, int NJ>
-__global__ void __launch_bounds__(PCX_LPP_WG, RCAP <= 8 ? 8 : (RCAP <= 12 ? PCX_LPP_MINB12 : 4))
+__global__ void __launch_bounds__(PCX_LPP_WG, RCAP <= 8 ? PCX_LPP_MINB8 : (RCAP <= 12 ? PCX_LPP_MINB12 : 4))
 k_tt_eval_lpp(const TTLppDim *__restrict__ tab, int d, const double *__restrict__ img,
               const double *__restrict__ pts, double *__restrict__ out, long N) {
     extern __shared__ double lds_lpp[];
