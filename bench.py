@@ -948,7 +948,57 @@ def run_rank(args) -> int:
                 return None
         if cwl.build_info:
             out["build"] = cwl.build_info
+        if name == "tt10d" and world == 1 and os.environ.get("PCX_BENCH_TT10D_FULL", "1") != "0":
+            try:
+                out["full_batch_one_gpu"] = tt10d_full(cwl)
+            except Exception as exc:                     # noqa: BLE001
+                sys.stderr.write(f"bench.py: tt10d full batch failed: {type(exc).__name__}: {exc}\n")
+                out["full_batch_one_gpu"] = {"error": f"{type(exc).__name__}: {exc}"}
         return out, cwl
+
+    def tt10d_full(cwl, shards=8, steps=10, warm=3):
+        """BASELINE config 5 whole on ONE GPU: 10^8 points x 10 doubles = 8 GB resident in HBM (288 GB per GPU), evaluated by
+        one launch per step -- what DESIGN.md section 2 sizes the device-resident entry points for.  The batch is the 8 shards
+        of the config's recipe (shard s: default_rng(99 + s), 12.5 M x 10), uploaded one after the other."""
+        per = 12_500_000
+        n = per * shards
+        d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+        chk(lib.pcx_dev_malloc(dev, n * cwl.d * 8, ctypes.byref(d_pts)))
+        chk(lib.pcx_dev_malloc(dev, n * 8, ctypes.byref(d_out)))
+        try:
+            t0 = time.perf_counter()
+            for s_ in range(shards):
+                blk = np.ascontiguousarray(uniform_points(cwl.domain, per, 99 + s_))
+                chk(lib.pcx_memcpy_h2d(dev, ctypes.c_void_p(d_pts.value + s_ * per * cwl.d * 8),
+                                       blk.ctypes.data_as(ctypes.c_void_p), blk.nbytes))
+            fill_s = time.perf_counter() - t0
+            st = cwl.stream()
+            for _ in range(warm):
+                cwl.launch(d_pts, n, d_out, st)
+            a, b = new_event(), new_event()
+            chk(lib.pcx_event_record(a, st))
+            for _ in range(steps):
+                cwl.launch(d_pts, n, d_out, st)
+            chk(lib.pcx_event_record(b, st))
+            chk(lib.pcx_stream_synchronize(st))
+            ms = elapsed_ms(a, b) / steps
+            tail = np.empty(1000)
+            chk(lib.pcx_memcpy_d2h(dev, tail.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(d_out.value + (n - 1000) * 8), 8000))
+            if not np.isfinite(tail).all():
+                raise SystemExit("non-finite results in the 10^8-point batch")
+            # shard 0's first rows must equal what the per-GPU companion batch (the same generator) gives
+            head = np.empty(4096)
+            chk(lib.pcx_memcpy_d2h(dev, head.ctypes.data_as(ctypes.c_void_p), d_out, head.nbytes))
+            same = bool(np.array_equal(head, cwl.model.eval_batch(uniform_points(cwl.domain, per, 99)[:4096])))
+            frac = cwl.flop_per_eval * n / (ms * 1e-3) / 1e12 / FP64_MFMA_PEAK_TFLOPS
+            return {"workload": "config 5 whole: 10^8 points x 10 dimensions (8 shards of 12.5 M, default_rng(99 + s)) resident on one GPU, one launch per step",
+                    "points_per_step": n, "device_bytes": n * (cwl.d + 1) * 8, "steps": steps, "warmup": warm,
+                    "ms_per_step": ms, "value": n / (ms * 1e-3), "unit": "point-evals/s", "roofline_frac": frac,
+                    "host_generate_and_upload_s_not_timed": fill_s, "first_rows_equal_the_per_gpu_batch": same}
+        finally:
+            lib.pcx_dev_free(dev, d_pts)
+            lib.pcx_dev_free(dev, d_out)
+            free_events()
 
     # the metric names both interpolants and BASELINE.json lists the Greeks run as a config:
     # the default (barycentric) run also times config 3 (TT) and config 4 (Greeks) with the

@@ -178,6 +178,11 @@ int pcx_bary_count_gemms(pcx_bary *h, const int32_t *derivs, int m, int64_t N, i
 int pcx_bary_set_group_tolerance(pcx_bary *h, double tol);
 int pcx_bary_set_group_span(pcx_bary *h, int span);
 int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
+/* Short MFMA plans (3-D tensors of 17 .. 65 nodes, 64^4: spline pieces, auto-N builds) lay their row tiles over the last two
+ * head dimensions instead of taking 16 consecutive rows, so the head weights need no row codes (k_bary_mfma_grid).
+ * info_out: {1 when the handle's MFMA plan is of that kind else 0, rows of the first tiled dimension per tile (1, 2, 4),
+ * row tiles, chunks}.  PCX_BARY_GRID=0 in the environment keeps every handle on the row-code form. */
+int pcx_bary_grid_info(pcx_bary *h, int32_t *info_out /* 4 ints */);
 int pcx_bary_stream(pcx_bary *h, void **stream);
 
 /* ---- piecewise (spline) interpolant ---------------------------------------- */

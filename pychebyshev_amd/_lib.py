@@ -86,6 +86,7 @@ SIGNATURES = {
     "pcx_bary_count_gemms": (_I, [_V, c_i32p, _I, _L, c_i32p]),
     "pcx_bary_set_group_tolerance": (_I, [_V, _D]),
     "pcx_bary_kernel_info": (_I, [_V, c_i32p]),
+    "pcx_bary_grid_info": (_I, [_V, c_i32p]),
     "pcx_bary_stream": (_I, [_V, c_vpp]),
     "pcx_spline_create": (_I, [_I, _I, c_i32p, c_f64p, c_vpp, _I, c_vpp]),
     "pcx_spline_destroy": (_I, [_V]),

@@ -86,6 +86,7 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
     h->pin.release();
     (void)hipFree(h->d_nodes); (void)hipFree(h->d_wts); (void)hipFree(h->d_diff);
     (void)hipFree(h->d_snodes);
+    (void)hipFree(h->d_gsnodes);
     (void)hipFree(h->d_rowcode); (void)hipFree(h->d_kcode);
     (void)hipFree(h->d_rowcode_hi); (void)hipFree(h->d_kcode_hi);
     (void)hipFree(h->d_rowcode_g0);
@@ -104,14 +105,18 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
 static int bary_pack(pcx_bary *h, DerivedTensor &dt) {
     if (!h->mfma_ok) return PCX_OK;
     const BaryMfmaPlan &p = h->plan;
-    size_t cnt = (size_t)p.MT * p.KS * 64;
+    size_t cnt = (size_t)(h->grid_ok ? h->gp.MT : p.MT) * p.KS * 64;
     DevBuf frag, slot;
     int rc = frag.alloc(cnt * sizeof(double));
     if (rc) return rc;
-    int blocks = (int)((cnt + 255) / 256);
-    hipLaunchKernelGGL(k_pack_fragments, dim3(blocks), dim3(256), 0, h->stream, dt.plain, frag.as<double>(),
-                       p.M, p.K, p.MT, p.KS);
-    HIP_TRY(hipGetLastError());
+    if (h->grid_ok) {
+        if ((rc = bary_pack_grid(h, dt.plain, frag.as<double>()))) return rc;
+    } else {
+        int blocks = (int)((cnt + 255) / 256);
+        hipLaunchKernelGGL(k_pack_fragments, dim3(blocks), dim3(256), 0, h->stream, dt.plain, frag.as<double>(),
+                           p.M, p.K, p.MT, p.KS);
+        HIP_TRY(hipGetLastError());
+    }
     if ((rc = slot.alloc(sizeof(double *)))) return rc;
     double *fp = frag.as<double>();
     HIP_TRY(hipMemcpy(slot.p, &fp, sizeof(double *), hipMemcpyHostToDevice));
@@ -219,8 +224,9 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
                 // 21 and 23 nodes: hipcc runs out of scalar registers on the odd row length (SGPR spills in the block,
                 // 0.37 / 0.36 of the peak against 0.39 / 0.44 on the MFMA kernel): available, not preferred
                 // 26 / 28 / 30 nodes: ahead in 2-D (26^2 0.40 against 0.21), behind the MFMA kernel in 3-D (30^3 0.32 against 0.42)
+                // round 4 (k_bary_mfma_grid): 20^3 0.45 -> 0.49 and 32^3 0.48 -> 0.55 on the MFMA kernel; 24^3 stays (0.54 vs 0.50)
                 h->sq_preferred = sq_auto && (d <= 3 || total <= kSmallTensorElems) && nl != 21 && nl != 23 &&
-                                  !(d >= 3 && nl > 24 && nl != 32);
+                                  !(d >= 3 && nl > 24) && !(d == 3 && nl == 20 && n_nodes[0] == 20);
             }
             // 2^e ~ 2 / (node span): exact to apply, keeps the prefix / suffix products of the weights in range
             std::vector<double> sn((size_t)sum_n);
@@ -330,6 +336,38 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
             }
         }
     }
+
+    // short plans: the grid form (bary_grid_kernels.h) -- unless the shape can share GEMMs between specs one order apart
+    // (dim-0 groups above), which needs the slab packing of the row-code form
+    if (h->mfma_ok && !h->g0_ok && !(h->plan.split > PCX_CODE_FIELDS || d - h->plan.split > PCX_CODE_FIELDS)) {
+        h->grid_ok = bary_plan_grid(h->dims, h->plan, h->gp);
+        if (h->grid_ok) {
+            h->nt = h->plan.KS > 32 ? 1 : 2;                       // the table is per wave and holds one part at a time
+            const size_t cap = (size_t)(h->gp.wpb == 4 ? 150 : 64) * 1024;
+            if (bary_grid_lds_bytes(h, h->nt) > cap) h->nt = 1;
+            if (bary_grid_lds_bytes(h, h->nt) > cap) h->grid_ok = false;
+        }
+        if (h->grid_ok) {
+            // division-free weights (as k_bary_small, bary_kernels.h): nodes scaled by 2^e ~ 2 / span per dimension
+            std::vector<double> sn((size_t)sum_n + PCX_MAX_DIMS, 0.0);
+            h->grid_prod = true;
+            for (int k = 0; k < d; ++k) {
+                const double *nd = nodes_cat + h->dims.off[k];
+                const double span = nd[n_nodes[k] - 1] - nd[0];
+                int e = 0;
+                if (span > 0.0 && std::isfinite(span)) (void)std::frexp(2.0 / span, &e);
+                const double sck = std::ldexp(1.0, e - 1);
+                sn[(size_t)sum_n + k] = sck;
+                for (int j = 0; j < n_nodes[k]; ++j) sn[h->dims.off[k] + j] = nd[j] * sck;
+                if (n_nodes[k] > 64) h->grid_prod = false;
+            }
+            static const bool prod_on = [] { const char *e = getenv("PCX_BARY_GRID_PROD"); return !(e && e[0] == '0'); }();
+            h->grid_prod = h->grid_prod && prod_on;
+            CREATE_TRY(hipMalloc((void **)&h->d_gsnodes, sn.size() * sizeof(double)));
+            CREATE_TRY(hipMemcpy(h->d_gsnodes, sn.data(), sn.size() * sizeof(double), hipMemcpyHostToDevice));
+        }
+    }
+    if (h->grid_ok) h->mfma4_ok = false;
 
     // value tensor (derivative spec all-zero) enters the cache at create
     DerivedTensor dt;
@@ -822,6 +860,7 @@ PCX_HIDDEN int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const 
     }
     if (variant == 2) {
         if (!h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
+        if (h->grid_ok) return bary_launch_grid(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
         // two column tiles per wave for throughput; one when the batch cannot fill the chip
         int nt = (N >= 65536) ? h->nt : 1;
         if (h->wide)
@@ -935,6 +974,17 @@ static double bary_pair_deviation(pcx_bary *h, const std::vector<int> &lower, in
     key.push_back(q);
     auto it = h->pair_dev.find(key);
     if (it != h->pair_dev.end()) return it->second;
+    // a probe that could not RUN (allocation, copy or launch failed) is not remembered: the pair stays ungrouped for this
+    // call and is measured again by the next one; PCX_BARY_PROBE_LOG=1 reports it
+    struct Forget {
+        pcx_bary *h; const std::vector<int> &key; bool keep = false;
+        ~Forget() {
+            if (keep) return;
+            h->pair_dev.erase(key);
+            (void)hipGetLastError();
+            if (getenv("PCX_BARY_PROBE_LOG")) fprintf(stderr, "[pcx] pair probe could not run: not cached, retried by the next call\n");
+        }
+    } forget{h, key};
     double &dev = h->pair_dev[key];
     dev = INFINITY;
     const int d = h->dims.d;
@@ -996,6 +1046,7 @@ static double bary_pair_deviation(pcx_bary *h, const std::vector<int> &lower, in
         diff = std::max(diff, std::fabs(R[2 * p] - R[2 * p + 1]));
     }
     if (std::isfinite(diff) && std::isfinite(scale)) dev = scale > 0.0 ? diff / scale : (diff == 0.0 ? 0.0 : INFINITY);
+    forget.keep = true;                           // measured (an infinite deviation included: non-finite model values)
     static const bool log = getenv("PCX_BARY_PROBE_LOG") != nullptr;
     if (log) {
         fprintf(stderr, "[pcx] pair probe (");
@@ -1016,6 +1067,8 @@ struct BaryGroup { int q; int base; std::vector<int> members; };
 //    dimension 0 first; q > 0 runs on the sub-model with q in front (bary_rot), own streams only (its column-permuted
 //    batch lives in the handle).  A pair is formed only when the probe has MEASURED the derived member within
 //    h->group_tol of its own GEMM (bary_pair_deviation).
+// N = the size of the CALL's batch: every piece of a pipelined host batch and every block of a fan-out is planned with it,
+// so that a (point, spec) gets the same rounding whichever piece it lands in.
 static void bary_plan_groups(pcx_bary *h, const int32_t *derivs, int m, long N, bool own_stream, std::vector<BaryGroup> &subs,
                              std::vector<char> &grouped) {
     const int d = h->dims.d;
@@ -1081,12 +1134,12 @@ static void bary_plan_groups(pcx_bary *h, const int32_t *derivs, int m, long N, 
 // Black-Scholes), as the reference's multi and batch paths do.  Caller holds h->mu.
 static int bary_launch_specs(pcx_bary *h, const int32_t *derivs, DerivedTensor *const *dts, int m,
                              const double *const *frag_tab, const double *d_pts, long N, double *d_out, long ostride,
-                             long ooff, hipStream_t st, Scratch *split_scratch) {
+                             long ooff, hipStream_t st, Scratch *split_scratch, long N_call = -1) {
     const int d = h->dims.d;
     std::vector<BaryGroup> subs;
     std::vector<char> grouped;
     const bool own_stream = st == h->stream || (h->stream2 && st == h->stream2);
-    bary_plan_groups(h, derivs, m, N, own_stream, subs, grouped);
+    bary_plan_groups(h, derivs, m, N_call > 0 ? N_call : N, own_stream, subs, grouped);
     // runs of consecutive ungrouped specs: ordinary launches
     for (int s = 0; s < m;) {
         if (grouped[s]) { ++s; continue; }
@@ -1215,8 +1268,10 @@ extern "C" int pcx_bary_eval_multi_batch_dev(pcx_bary *h, const double *d_pts, i
     PCX_API_END
 }
 
+// N_call: the batch of the API call this block belongs to (fan-out blocks pass the whole call's N), -1 = N itself
 static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32_t *derivs, int m,
-                          double *out) {
+                          double *out, int64_t N_call = -1) {
+    if (N_call < N) N_call = N;
     if (!h) return fail(PCX_ERR_INVALID, "handle is NULL");
     if (N < 0 || m < 1) return fail(PCX_ERR_INVALID, "bad N or m");
     if (N > 0 && (!pts || !out)) return fail(PCX_ERR_INVALID, "NULL buffer");
@@ -1229,7 +1284,7 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
         for (int s0 = 0; s0 < m; s0 += kMaxSpecs) {
             const int mc = std::min(kMaxSpecs, m - s0);
             part.resize((size_t)N * mc);
-            int rc = bary_eval_host(h, pts, N, derivs + (size_t)s0 * d0, mc, part.data());
+            int rc = bary_eval_host(h, pts, N, derivs + (size_t)s0 * d0, mc, part.data(), N_call);
             if (rc) return rc;
             for (int64_t i = 0; i < N; ++i)
                 memcpy(out + (size_t)i * m + s0, part.data() + (size_t)i * mc, (size_t)mc * sizeof(double));
@@ -1296,7 +1351,8 @@ static int bary_eval_host(pcx_bary *h, const double *pts, int64_t N, const int32
             if (rc) return rc;
             double *dp = (double *)sp.ptr, *dout = (double *)so.ptr;
             HIP_TRY(hipMemcpyAsync(dp, pts + (size_t)start * d, (size_t)cnt * d * sizeof(double), hipMemcpyHostToDevice, st));
-            rc = bary_launch_specs(h, derivs, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial);
+            rc = bary_launch_specs(h, derivs, dts.data(), m, frag_tab, dp, cnt, dout, m, 0, st, second ? nullptr : &h->s_partial,
+                                   (long)N_call);
             if (rc) return rc;
             if (!piped) {                             // single slot: download here, drain before its buffers are reused
                 HIP_TRY(hipMemcpyAsync(out + (size_t)start * m, dout, (size_t)cnt * m * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -1431,7 +1487,7 @@ extern "C" int pcx_bary_group_eval_multi_batch(pcx_bary *const *handles, int n_h
     if (!fanout_arrays_locked(hp, pin, pts, (size_t)N * d * sizeof(double), out, (size_t)N * m * sizeof(double)))
         return bary_eval_host(handles[0], pts, N, derivs, m, out);
     return fan_out(n_handles, N, [&](int g, int64_t lo, int64_t cnt) {
-        return bary_eval_host(handles[g], pts + (size_t)lo * d, cnt, derivs, m, out + (size_t)lo * m);
+        return bary_eval_host(handles[g], pts + (size_t)lo * d, cnt, derivs, m, out + (size_t)lo * m, N);
     });
     PCX_API_END
 }
@@ -1518,11 +1574,22 @@ extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
     PCX_API_BEGIN
     if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
     { const int keep = h->variant; h->variant = 0; info[0] = bary_effective_variant(h); h->variant = keep; }
-    info[1] = h->mfma_ok ? h->plan.MT : 0;
+    info[1] = h->mfma_ok ? (h->grid_ok ? h->gp.MT : h->plan.MT) : 0;
     info[2] = h->mfma_ok ? h->plan.KS : 0;
     info[3] = h->mfma_ok ? (int32_t)mfma_lds_bytes(h->dims, h->nt) : (256 / h->lpp) * h->dims.sum_n * 8;
     info[4] = h->mfma_ok ? 64 * h->nt : 256 / h->lpp;
     info[5] = h->mfma_ok ? h->plan.split : h->dims.d - 1;
+    return PCX_OK;
+    PCX_API_END
+}
+
+extern "C" int pcx_bary_grid_info(pcx_bary *h, int32_t *info) {
+    PCX_API_BEGIN
+    if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
+    info[0] = h->grid_ok ? 1 : 0;
+    info[1] = h->grid_ok ? h->gp.RA : 0;
+    info[2] = h->grid_ok ? h->gp.MT : 0;
+    info[3] = h->grid_ok ? h->gp.nchunks : 0;
     return PCX_OK;
     PCX_API_END
 }

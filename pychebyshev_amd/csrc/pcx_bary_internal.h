@@ -45,6 +45,12 @@ struct pcx_bary {
     unsigned *d_rowcode = nullptr, *d_kcode = nullptr;
     unsigned *d_rowcode_hi = nullptr, *d_kcode_hi = nullptr;   // fields 4..7 (wide plans only)
     bool wide = false;      // more than four head or tail dimensions
+    // short plans: row tiles = RA x RB blocks of the last two head dimensions, no row codes (bary_grid_kernels.h);
+    // the fragment image of every derivative tensor is then packed in that order
+    bool grid_ok = false;
+    BaryGridPlan gp;
+    double *d_gsnodes = nullptr;     // nodes times a power of two per dimension, then the PCX_MAX_DIMS scales themselves
+    bool grid_prod = false;          // every dimension <= 64 nodes: division-free weights (grid_weights_prod)
     // dim-0 groups (BaryG0): specs differing only in their dim-0 order share one slab-packed GEMM
     bool g0_ok = false;
     int g0_tps = 0;                  // row tiles per dim-0 slab
@@ -84,6 +90,13 @@ struct pcx_bary {
 };
 
 static const int kMaxSpecs = 64;      // derivative specs evaluated by one launch (grid.z)
+
+// pcx_bary_grid.hip
+PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, BaryGridPlan &gp);
+PCX_HIDDEN int bary_pack_grid(pcx_bary *h, const double *plain, double *frag);
+PCX_HIDDEN size_t bary_grid_lds_bytes(const pcx_bary *h, int nt);
+PCX_HIDDEN int bary_launch_grid(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
+                                long ostride, long ooff, hipStream_t st, Scratch *split_scratch, const int *perm);
 
 // pcx_bary.hip
 PCX_HIDDEN int bary_get_tensor(pcx_bary *h, const int32_t *deriv, DerivedTensor **out);

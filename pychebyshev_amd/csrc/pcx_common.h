@@ -38,6 +38,23 @@ struct BaryMfmaPlan {
     int rows;       // table rows (= sum_n + 2)
 };
 
+// k_bary_mfma_grid (bary_grid_kernels.h): row tiles = RA x RB blocks of the last two head dimensions A, B
+struct BaryGridPlan {
+    int RA;          // A rows per tile: 1, 2 or 4 (RB = 16 / RA rows of B)
+    int gbs;         // log2(GB), GB = 4 / RA lane groups span B
+    int nA, nB;      // nodes of the two tiled head dimensions (dims split-2 and split-1)
+    int TA, TB;      // tiles along A and B
+    int rowA, rowB;  // first table row of A and of B
+    int nouter;      // head dimensions in front of A: 0, 1 or 2
+    int no1;         // nodes of the second outer dimension (1 when there is none)
+    int rowo0, rowo1;// first table rows of the outer dimensions
+    int nchunks;     // O * TA
+    int hrows;       // head rows + the slack the padded B index of a last tile reads (zeroed)
+    int trows;       // table rows per wave: max(hrows, tail rows + 1)
+    int wpb;         // waves per workgroup: 1 (fragment image in L2) or 4 (large tensors: the waves share the stream)
+    int MT;          // nchunks * TB row tiles
+};
+
 // A "dim-0 group" of a multi-spec launch: specs that differ only in their derivative order along dimension 0
 // share ONE contraction of dimensions 1 .. d-1 (reference vectorized_eval_multi, barycentric.py:1098-1110:
 // contract the later dimensions, THEN apply D_0, then contract dimension 0).  The GEMM rows are laid out in

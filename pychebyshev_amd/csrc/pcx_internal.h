@@ -204,18 +204,20 @@ struct HostPin {
     // page-locked by the caller (pcx_host_register, hipHostMalloc)
     bool pin(const void *p, size_t bytes, void **slot) {
         if (!p || !bytes) return true;
-        hipPointerAttribute_t at{};
-        if (hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost) {
-            hipPointerAttribute_t ae{};
-            if (hipPointerGetAttributes(&ae, (const char *)p + bytes - 1) == hipSuccess && ae.type == hipMemoryTypeHost) return true;
-        }
-        (void)hipGetLastError();
-        if (hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable) == hipSuccess) {
+        // always ask the runtime to register the WHOLE range: it refuses a range that is already page-locked
+        // (hipErrorHostMemoryAlreadyRegistered: by the caller, or memory from hipHostMalloc) -- then both ends must be
+        // host-accessible page-locked memory; anything else (a partial overlap with another registration, ...) is "not locked"
+        const hipError_t e = hipHostRegister(const_cast<void *>(p), bytes, hipHostRegisterPortable);
+        if (e == hipSuccess) {
             *slot = const_cast<void *>(p);
             return true;
         }
         (void)hipGetLastError();
-        return false;
+        hipPointerAttribute_t at{}, ae{};
+        const bool both = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeHost &&
+                          hipPointerGetAttributes(&ae, (const char *)p + bytes - 1) == hipSuccess && ae.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        return both;
     }
     ~HostPin() {
         if (a) (void)hipHostUnregister(a);

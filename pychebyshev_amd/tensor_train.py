@@ -477,7 +477,7 @@ class ChebyshevTT(ErgonomicsMixin):
             raise RuntimeError("Call build() before using this method.")
 
     # ---------------------------------------------------------------- device plumbing
-    def to_device(self, device: int | None = None, *, devices=None) -> "ChebyshevTT":
+    def to_device(self, device: int | None = None, *, devices=None, pin: bool = True) -> "ChebyshevTT":
         """Upload the cores to GPU ``device``; ``devices`` (list or ``"all"``; default ``PCX_DEVICES``) replicates
         them on several GPUs of this process, and large host-pointer batches are split into one contiguous row
         block per device (``pcx_tt_group_eval_batch``), as ``ChebyshevApproximation.to_device`` describes."""
@@ -498,6 +498,10 @@ class ChebyshevTT(ErgonomicsMixin):
         self._device_tt = _DeviceTT(self, dev)
         self._fanout = [self._device_tt] + [_DeviceTT(self, g) for g in (devices or [])[1:]]
         self._fanout_devices = list(devices) if devices else None
+        # fan-out only: page-lock the caller's arrays for the duration of each call (hipHostRegister over the points and the
+        # result: copies at PCIe rate, at the price of a registration per call); pin=False fans out only over arrays the
+        # caller page-locked itself (pcx_host_register) and sends everything else through the first device
+        self._fanout_pin = bool(pin)
         return self
 
     def invalidate_device_cache(self) -> None:
@@ -538,7 +542,8 @@ class ChebyshevTT(ErgonomicsMixin):
         use = max(1, min(len(group), pts.shape[0] // _lib.FANOUT_MIN_ROWS_PER_DEVICE)) if group and group[0] is t else 1
         if use > 1:
             harr, keep = _lib.handle_array([g.handle for g in group[:use]])
-            _lib.check(t.lib.pcx_tt_group_eval_batch(harr, use, _lib.p_f64(pts), pts.shape[0], _lib.p_f64(out), 1), t.lib)
+            _lib.check(t.lib.pcx_tt_group_eval_batch(harr, use, _lib.p_f64(pts), pts.shape[0], _lib.p_f64(out),
+                                                     1 if getattr(self, "_fanout_pin", True) else 0), t.lib)
         else:
             _lib.check(t.lib.pcx_tt_eval_batch(t.handle, _lib.p_f64(pts), pts.shape[0], _lib.p_f64(out)), t.lib)
         return out

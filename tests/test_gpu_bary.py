@@ -825,7 +825,7 @@ def test_lane_per_point_kernel_for_small_tensors(oracle_mod, shape):
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
     sq = (d >= 2 and shape[-1] == shape[-2] and (4 <= shape[-1] <= 24 or shape[-1] in (26, 28, 30, 32)) and (d <= 3 or T.size <= 4096)
-          and shape[-1] not in (21, 23) and not (d >= 3 and shape[-1] in (26, 28, 30)))
+          and shape[-1] not in (21, 23) and not (d >= 3 and shape[-1] in (26, 28, 30, 32)) and shape != (20, 20, 20))
     assert info[0] == (5 if sq else (4 if (T.size <= 4096 and shape[-1] <= 48) else 2))
     specs = [[0] * d]
     if all(v > 2 for v in shape):
@@ -985,7 +985,8 @@ def test_square_trailing_lane_per_point_kernel(oracle_mod, shape):
     info = _lib.i32(np.zeros(6))
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
-    assert info[0] == (5 if shape != (3, 26, 26) else 4)       # d <= 3 (26..30 nodes: 2-D only), or up to 4096 elements
+    # d <= 3 (26..32 nodes: 2-D only; 20^3: the MFMA grid kernel since round 4), or up to 4096 elements
+    assert info[0] == {(3, 26, 26): 4, (20, 20, 20): 2}.get(shape, 5)
     _set_kernel(c, 5)
     specs = [[0] * d, [1] + [0] * (d - 1), [0] * (d - 1) + [2], [0] * (d - 2) + [1, 1]]
     for npts in (1, 63, 64, 65, 3000):
@@ -1012,3 +1013,98 @@ def test_square_trailing_lane_per_point_kernel(oracle_mod, shape):
     assert c.vectorized_eval_batch(pts[:1], [0] * d)[0] == T[tuple([-1] * d)]      # grid point: the tensor entry exactly
     # a point's value does not depend on the batch it sits in
     assert np.array_equal(c.vectorized_eval_batch(pts[100:133], specs[0]), c.vectorized_eval_batch(pts, specs[0])[100:133])
+
+
+def _grid_info(c):
+    m = c._model()
+    info = _lib.i32(np.zeros(4))
+    assert m.lib.pcx_bary_grid_info(m.handle, _lib.p_i32(info)) == 0
+    return [int(v) for v in info]
+
+
+@pytest.mark.parametrize("shape,dom", [
+    ((21, 21, 21), [[0, 1], [-1, 1], [2, 5]]),                  # RA = 2: 11 x 3 tiles, 6 k-steps
+    ((17, 19, 23), [[0, 1], [-1, 1], [2, 5]]),                  # unequal node counts, both tiled dimensions padded
+    ((30, 30, 30), [[-1, 1]] * 3),
+    ((40, 40, 40), [[-1, 1]] * 3),                              # no padding at all: 100 tiles of 10 k-steps
+    ((65, 65, 65), [[0, 2]] * 3),                               # 17 k-steps and padded tiles: stays on the row-code kernel
+    ((16, 16, 64), [[0, 2]] * 3),                               # 16 k-steps, nothing padded: grid
+    ((17, 12, 16, 52), [[0, 1]] * 4),                           # 13 k-steps, one outer dimension, nothing padded
+    ((18, 5, 20, 40), [[0, 1]] * 4),                            # one outer head dimension (18 > 16 nodes in front: no dim-0 groups)
+    ((17, 4, 16, 12, 33), [[0, 1]] * 5),                        # two outer head dimensions
+    ((20, 24), [[0, 1], [0, 2]]),                               # d = 2: head of one dimension -> not a grid plan (stays as it was)
+])
+def test_grid_plans_against_oracle(oracle_mod, shape, dom):
+    """short MFMA plans on k_bary_mfma_grid (row tiles over the last two head dimensions, no row codes):
+    value and derivative specs vs the oracle at the 1e-12 bar for a small batch (split launch, one column tile per
+    wave) and a large one (two column tiles, no split), multi-spec launches, exact-node and corner rows; a point's
+    value does not depend on the batch it is evaluated in."""
+    rng = np.random.default_rng(sum(shape) + 5)
+    T = rng.standard_normal(shape)
+    d = len(shape)
+    c = ChebyshevApproximation.from_values(T, d, dom, list(shape))
+    _set_kernel(c, 2)
+    gi = _grid_info(c)
+    if d >= 3 and shape != (65, 65, 65):
+        assert gi[0] == 1, f"expected a grid plan for {shape}: {gi}"
+    if shape == (65, 65, 65):
+        assert gi[0] == 0
+    if d == 2:
+        assert gi[0] == 0
+    n_small, n_big = 777, 66_000
+    pts = np.column_stack([rng.uniform(lo, hi, n_big) for lo, hi in dom])
+    for k in range(d):
+        pts[k, k] = c.nodes[k][rng.integers(0, shape[k])]              # rows exactly on nodes
+        pts[d + k, k] = c.nodes[k][shape[k] - 1]                       # ... on the LAST node of a (padded) dimension
+    pts[-1] = [lo for lo, hi in dom]
+    pts[-2] = [hi for lo, hi in dom]
+    pts[-3] = [lo if k % 2 else hi for k, (lo, hi) in enumerate(dom)]
+    om = _oracle_model(oracle_mod, c)
+    specs = [[0] * d, [1] + [0] * (d - 1), [0] * (d - 1) + [2], [0] * (d - 2) + [1, 1]]
+    sub = np.r_[0:300, n_big - 300:n_big]
+    big = {}
+    for s in specs:
+        y = c.vectorized_eval_batch(pts, s)
+        big[tuple(s)] = y
+        assert_parity(y[sub], oracle_mod.bary_eval_batch(om, pts[sub], s), 1e-12, f"grid {shape} {s} big", spec_point_tol(s),
+                      floor=np.max(np.abs(T)))
+        small = c.vectorized_eval_batch(pts[:n_small], s)
+        assert np.array_equal(small, y[:n_small]), f"{shape} {s}: small batch differs from the same rows of the large one"
+        one = c.vectorized_eval_batch(pts[n_big - 1:], s)
+        assert one[0] == y[-1]
+    multi = c.vectorized_eval_multi_batch(pts[:5000], specs)
+    for j, s in enumerate(specs):
+        assert np.array_equal(multi[:, j], big[tuple(s)][:5000]), f"{shape} multi-spec column {s}"
+    # grid points return the tensor entry exactly (one-hot weights, zero-padded tiles contribute +0)
+    idx = [rng.integers(0, n, 64) for n in shape]
+    gp_ = np.column_stack([np.asarray(c.nodes[k])[idx[k]] for k in range(d)])
+    assert np.array_equal(c.vectorized_eval_batch(gp_, [0] * d), T[tuple(idx)])
+    # NaN coordinates give NaN, nothing else does
+    bad = pts[:64].copy()
+    bad[3, d - 1] = np.nan
+    bad[5, 0] = np.nan
+    yb = c.vectorized_eval_batch(bad, [0] * d)
+    assert np.isnan(yb[3]) and np.isnan(yb[5]) and np.isfinite(np.delete(yb, [3, 5])).all()
+
+
+def test_grid_plan_equals_row_code_plan_to_rounding(oracle_mod, monkeypatch):
+    """The same model on the row-code form (PCX_BARY_GRID=0 at create) and on the grid form: both within the bar of the
+    oracle, and of each other at rounding level."""
+    rng = np.random.default_rng(77)
+    shape = (24, 24, 24)
+    T = rng.standard_normal(shape)
+    dom = [[-1, 1]] * 3
+    pts = np.column_stack([rng.uniform(lo, hi, 70_000) for lo, hi in dom])
+    res = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("PCX_BARY_GRID", flag)
+        c = ChebyshevApproximation.from_values(T, 3, dom, list(shape))
+        _set_kernel(c, 2)
+        res[flag] = (c.vectorized_eval_batch(pts, [0, 0, 0]), c.vectorized_eval_batch(pts, [0, 1, 0]), _grid_info(c)[0])
+    assert res["1"][2] == 1
+    om = _oracle_model(oracle_mod, c)
+    for j, s in enumerate(([0, 0, 0], [0, 1, 0])):
+        ref = oracle_mod.bary_eval_batch(om, pts[:2000], s)
+        for flag in ("1", "0"):
+            assert_parity(res[flag][j][:2000], ref, 1e-12, f"grid={flag} {s}", spec_point_tol(s), floor=np.max(np.abs(T)))
+        assert np.max(np.abs(res["1"][j] - res["0"][j])) <= 1e-12 * np.max(np.abs(res["0"][j]))

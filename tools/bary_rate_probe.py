@@ -26,8 +26,11 @@ def rate(shape, npts, variant=0):
     c.to_device()
     m = c._model()
     lib = m.lib
-    info = (ctypes.c_int32 * 6)()
+    info = (ctypes.c_int32 * 10)()
     _lib.check(lib.pcx_bary_kernel_info(m.handle, info), lib)
+    ginfo = (ctypes.c_int32 * 4)()
+    _lib.check(lib.pcx_bary_grid_info(m.handle, ginfo), lib)
+    info[6], info[7] = ginfo[0], ginfo[1]          # grid plan (round 4): 1 / rows of the first tiled dimension per tile
     if variant and lib.pcx_bary_set_kernel(m.handle, variant) != 0:
         return (float("nan"),) * 3, list(info)
     pts = rng.uniform(-1, 1, (npts, d))
@@ -60,13 +63,17 @@ def rate(shape, npts, variant=0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--points", type=int, default=1_000_000)
+    ap.add_argument("--only", default="", help="comma list of shapes, e.g. 21x21x21,40x40x40")
     a = ap.parse_args()
-    print(f"{'shape':<16} {'auto kernel':<26} {'pts/s':>11} {'fp64':>6} {'hbm':>6}   {'lane/pt pts/s':>13} {'fp64':>6}   "
+    print(f"{'shape':<16} {'auto kernel':<34} {'pts/s':>11} {'fp64':>6} {'hbm':>6}   {'lane/pt pts/s':>13} {'fp64':>6}   "
           f"{'sq l/pt pts/s':>13} {'fp64':>6}   {'mfma pts/s':>11} {'fp64':>6}   {'rows pts/s':>11} {'fp64':>6}")
     shapes = [(11,) * 5, (7,) * 5, (5,) * 6, (15,) * 4, (21,) * 3, (33, 33), (64, 64), (200,), (12, 12), (9, 7, 6),
               (6, 6, 6, 6), (8, 8, 8), (16, 16, 16), (11, 11, 11), (9, 11, 13, 7), (4,) * 8, (3,) * 10, (6, 11, 11, 11, 11),
-              (11, 11, 11, 11, 6), (16,) * 4, (20,) * 3, (17,) * 3, (24,) * 3, (30,) * 3, (32,) * 3, (40,) * 3, (10, 10, 10, 10),
-              (12, 12, 12, 12), (8, 8, 8, 8), (24, 24), (32, 32), (65,) * 3, (64,) * 4]
+              (11, 11, 11, 11, 6), (16,) * 4, (20,) * 3, (17,) * 3, (18,) * 3, (19,) * 3, (22,) * 3, (23,) * 3, (24,) * 3, (26,) * 3,
+              (28,) * 3, (30,) * 3, (32,) * 3, (40,) * 3, (48,) * 3, (10, 10, 10, 10), (12, 12, 12, 12), (8, 8, 8, 8), (24, 24),
+              (32, 32), (65,) * 3, (64,) * 4]
+    if a.only:
+        shapes = [tuple(int(v) for v in t.split("x")) for t in a.only.split(",")]
     for shape in shapes:
         size = int(np.prod(shape))
         npts = 4 * a.points if size <= 2000 else (a.points if size < 4_000_000 else a.points // 8)
@@ -75,9 +82,12 @@ def main():
         sq, _ = rate(shape, npts, variant=5)
         mfma, _ = rate(shape, npts, variant=2)
         rows, _ = rate(shape, npts // 4 if size > 100_000 else npts, variant=1)
-        kern = {4: "lane-per-point", 5: "lane-per-point sq", 1: "rows"}.get(info[0], f"mfma MT={info[1]} KS={info[2]} split={info[5]}")
+        kern = {4: "lane-per-point", 5: "lane-per-point sq", 1: "rows"}.get(
+            info[0], f"mfma{' grid' + str(info[7]) if info[6] else ''} MT={info[1]} KS={info[2]} split={info[5]}")
+        if info[0] != 2 and info[6]:
+            kern += f" (mfma: grid{info[7]})"
         name = "x".join(str(n) for n in shape) if len(set(shape)) > 1 else f"{shape[0]}^{len(shape)}"
-        print(f"{name:<16} {kern:<26} {auto[0]:11.4e} {auto[1]:6.3f} {auto[2]:6.3f}   {small[0]:13.4e} {small[1]:6.3f}   "
+        print(f"{name:<16} {kern:<34} {auto[0]:11.4e} {auto[1]:6.3f} {auto[2]:6.3f}   {small[0]:13.4e} {small[1]:6.3f}   "
               f"{sq[0]:13.4e} {sq[1]:6.3f}   {mfma[0]:11.4e} {mfma[1]:6.3f}   {rows[0]:11.4e} {rows[1]:6.3f}")
 
 

@@ -15,12 +15,14 @@ sys.path.insert(0, ROOT)
 from pychebyshev_amd import ChebyshevApproximation, _lib  # noqa: E402
 
 shape = [int(a) for a in sys.argv[1:]] or [12, 12]
-npts = 4_000_000
+npts = int(os.environ.get("PCX_ONCE_POINTS", "4000000"))
 d = len(shape)
 rng = np.random.default_rng(7)
 c = ChebyshevApproximation.from_values(rng.standard_normal(shape), d, [[-1.0, 1.0]] * d, shape)
 m = c._model()
 lib = m.lib
+if os.environ.get("PCX_ONCE_VARIANT"):          # force a kernel form (pcx_bary_set_kernel)
+    _lib.check(lib.pcx_bary_set_kernel(m.handle, int(os.environ["PCX_ONCE_VARIANT"])), lib)
 pts = rng.uniform(-1, 1, (npts, d))
 d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
 _lib.check(lib.pcx_dev_malloc(m.device, pts.nbytes, ctypes.byref(d_pts)), lib)
