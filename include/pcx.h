@@ -10,8 +10,9 @@
  *
  * Conventions
  *   - extern "C", plain pointers and sizes; no C++/torch types cross the boundary.
- *   - return 0 (PCX_OK) or a negative PCX_ERR_* code; never throws.  pcx_last_error()
- *     returns a thread-local description of the last failure on the calling thread.
+ *   - return 0 (PCX_OK) or a negative PCX_ERR_* code; never throws: every entry point catches what its C++ body may
+ *     raise (std::bad_alloc -> PCX_ERR_NOMEM, anything else -> PCX_ERR_HIP; csrc/pcx_internal.h, PCX_API_BEGIN / _END).
+ *     pcx_last_error() returns a thread-local description of the last failure on the calling thread.
  *   - all floating point is IEEE float64; tensors are C-order (last index fastest);
  *     `pts` is an (N, d) row-major array, exactly the ndarray the reference takes.
  *   - the library copies model data at create; callers keep ownership of every buffer

@@ -129,12 +129,19 @@ k_tt_fd_lpp(const TTLppDim *__restrict__ tab, int d, int vrows, const double *__
 #pragma unroll
             for (int i = 0; i < PCX_FD_MAX_ACTIVE; ++i) xl[i] = i < sp.nact ? fd_coord(xb[i], sp.h[i], sp.order[i], dig[i]) : 0.0;
             vl[0] = 1.0;
-            for (int k = 0; k < d; ++k) {
+            // the coordinate of dimension k + 1 is fetched (and replaced, where that dimension is differenced) while
+            // dimension k is contracted, as in k_tt_eval_lpp
+            auto coord = [&](int k) {
                 double xu = row[ct[k].col];
 #pragma unroll
                 for (int i = 0; i < PCX_FD_MAX_ACTIVE; ++i)
                     if (i < sp.nact && sp.dim[i] == k) xu = xl[i];
-                const double x = __builtin_fma(xu - ct[k].lo, ct[k].scale, -1.0);    // as k_tt_eval_lpp
+                return xu;
+            };
+            double xn = coord(0);
+            for (int k = 0; k < d; ++k) {
+                const double x = __builtin_fma(xn - ct[k].lo, ct[k].scale, -1.0);    // as k_tt_eval_lpp
+                if (k + 1 < d) xn = coord(k + 1);
                 const pcx_lpp_cptr G = cimg + ct[k].off;
                 const int rl = ct[k].rl, rr = ct[k].rr;
                 if constexpr (NJ > 0) {

@@ -316,8 +316,98 @@ def slider_case(rng, stats):
     return fails
 
 
+
+def grid_case(rng, stats):
+    """Round 4: mid-size tensors (3-D ... 5-D, 14 ... 40 nodes in the tiled dimensions) on the MFMA kernel -- the shapes
+    k_bary_mfma_grid takes (and the ones its planner declines), a small and a large batch, value and derivative specs,
+    exact nodes, corners; each against the oracle and the small batch against the same rows of the large one."""
+    d = int(rng.choice([3, 3, 3, 4, 5]))
+    while True:
+        shape = tuple(int(rng.integers(2, 41 if k >= d - 3 else 9)) for k in range(d))
+        if rng.random() < 0.3:
+            nl = int(rng.integers(14, 41))
+            shape = shape[:-3] + (nl, nl, nl)
+        if 2_000 <= np.prod(shape) <= 150_000:
+            break
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.choice([0.0, -3.0, 100.0], d), rng.choice([0.01, 1.0, 25.0], d))]
+    T = rng.standard_normal(shape) * float(rng.choice([1e-4, 1.0, 1e3]))
+    c = ChebyshevApproximation.from_values(T, d, dom, list(shape), max_derivative_order=2)
+    m = c._model()
+    if m.lib.pcx_bary_set_kernel(m.handle, 2) != 0:
+        return []
+    gi = _lib.i32(np.zeros(4))
+    m.lib.pcx_bary_grid_info(m.handle, _lib.p_i32(gi))
+    stats["grid_plans"] = stats.get("grid_plans", 0) + int(gi[0])
+    n_big = int(rng.choice([66_000, 70_001]))
+    pts = np.column_stack([rng.uniform(lo, hi, n_big) for lo, hi in dom])
+    for _ in range(8):
+        k = int(rng.integers(d))
+        pts[int(rng.integers(0, 400)), k] = c.nodes[k][int(rng.integers(shape[k]))]
+    pts[0] = [lo for lo, _ in dom]
+    pts[1] = [hi for _, hi in dom]
+    spec = [0] * d
+    if rng.random() < 0.6:
+        k = int(rng.integers(d))
+        if shape[k] > 3:
+            spec[k] = int(rng.integers(1, 3))
+    om = oracle.BaryModel(c.nodes, c.weights, c.diff_matrices, c.tensor_values)
+    sub = np.r_[0:400, n_big - 200:n_big]
+    ref = oracle.bary_eval_batch(om, pts[sub], spec)
+    Td = T
+    for k in range(d):
+        for _ in range(spec[k]):
+            Td = np.moveaxis(np.moveaxis(Td, k, -1) @ c.diff_matrices[k].T, -1, k)
+    scale = max(float(np.max(np.abs(ref))), float(np.max(np.abs(Td))), 1e-300)
+    big = c.vectorized_eval_batch(pts, spec)
+    small = c.vectorized_eval_batch(pts[:333], spec)
+    err = float(np.max(np.abs(big[sub] - ref))) / scale if np.isfinite(big).all() else float("inf")
+    stats["grid_launches"] = stats.get("grid_launches", 0) + 2
+    stats["grid_worst"] = max(stats.get("grid_worst", 0.0), err)
+    fails = []
+    if not err <= 1e-12:
+        fails.append(f"grid shape={shape} dom={dom} spec={spec} plan={list(gi)} err={err:.3e}")
+    if not np.array_equal(small, big[:333]):
+        fails.append(f"grid shape={shape} spec={spec} plan={list(gi)}: small batch differs from the same rows of the large one")
+    return fails
+
+
+def ttfd_case(rng, stats):
+    """Round 4: device-side finite-difference Greeks (pcx_tt_eval_multi_batch) against the NumPy column traversal of the
+    same rules, bit for bit: random models (lane-per-point and MFMA forms), dim_order, specs with up to three differenced
+    dimensions, rows in the boundary band and on the corners."""
+    d = int(rng.integers(1, 9))
+    rmax = int(rng.choice([3, 8, 12, 16, 20]))
+    ranks = [1] + [int(rng.integers(1, rmax + 1)) for _ in range(d - 1)] + [1]
+    n = [int(rng.integers(2, 17)) for _ in range(d)]
+    cores = [rng.standard_normal((ranks[k], n[k], ranks[k + 1])) / np.sqrt(ranks[k] * n[k]) for k in range(d)]
+    dom = [[float(a), float(a + w)] for a, w in zip(rng.uniform(-50, 50, d), rng.choice([1e-2, 1.0, 40.0], d))]
+    order = [int(v) for v in rng.permutation(d)] if rng.random() < 0.5 else None
+    tt = ChebyshevTT.from_coeff_cores(cores, dom, dim_order=order)
+    npts = int(rng.choice([1, 63, 64, 65, 1000, 5000]))
+    st = np.column_stack([rng.uniform(lo, hi, npts) for lo, hi in dom])
+    for r in range(min(npts, 2 * d)):                       # rows inside the 1.5 h band / on the boundary
+        k = r % d
+        st[r, k] = dom[k][0] + (dom[k][1] - dom[k][0]) * (1e-5 if r < d else 1.0)
+    pts = st
+    if order is not None:
+        pts = np.empty_like(st)
+        pts[:, order] = st
+    specs = [[0] * d]
+    for _ in range(int(rng.integers(1, 6))):
+        sp = [0] * d
+        for k in rng.choice(d, size=min(d, int(rng.integers(1, 4))), replace=False):
+            sp[int(k)] = int(rng.integers(1, 3))
+        specs.append(sp)
+    got = tt.eval_multi_batch(pts, specs)
+    want = tt._eval_multi_batch_host(pts, specs)
+    stats["ttfd_columns"] = stats.get("ttfd_columns", 0) + len(specs)
+    same = np.array_equal(got, want) or (np.isnan(got) == np.isnan(want)).all() and np.array_equal(np.nan_to_num(got), np.nan_to_num(want))
+    return [] if same else [f"ttfd d={d} ranks={ranks} n={n} order={order} N={npts} specs={specs}: "
+                            f"max |device - host| = {np.nanmax(np.abs(got - want)):.3e}"]
+
+
 KINDS = {"bary": bary_case, "tt": tt_case, "spline": spline_case, "multi": multi_case, "slider": slider_case,
-         "group": group_case}
+         "group": group_case, "grid": grid_case, "ttfd": ttfd_case}
 
 
 def main():
@@ -334,7 +424,7 @@ def main():
         seed = seed0 + cases
         rng = np.random.default_rng(seed)
         try:
-            kind = args.kind or ("bary", "tt", "bary", "tt", "spline", "multi", "slider", "group")[cases % 8]
+            kind = args.kind or ("bary", "tt", "grid", "ttfd", "bary", "tt", "spline", "multi", "slider", "group")[cases % 10]
             fails = KINDS[kind](rng, stats)
         except Exception as exc:                       # noqa: BLE001 -- an exception is a finding too
             fails = [f"exception {type(exc).__name__}: {exc}"]
@@ -354,7 +444,9 @@ def main():
           f"spline {stats.get('spline_worst', 0.0):.2e}, multi-spec {stats.get('multi_worst', 0.0):.2e}, "
           f"slider {stats.get('slider_worst', 0.0):.2e} over {stats.get('slider_launches', 0)} sliders, dim-0 groups "
           f"{stats.get('group_worst', 0.0):.2e} over {stats.get('group_launches', 0)} columns, {stats.get('group_shared', 0)} of them on a shared "
-          f"contraction (bar 1e-12); "
+          f"contraction (bar 1e-12); grid-plan shapes {stats.get('grid_worst', 0.0):.2e} over {stats.get('grid_launches', 0)} launches "
+          f"({stats.get('grid_plans', 0)} models on k_bary_mfma_grid); device FD Greeks = host traversal bit for bit on "
+          f"{stats.get('ttfd_columns', 0)} columns; "
           f"failures: {len(failures)}")
     return 1 if failures else 0
 

@@ -19,12 +19,20 @@ import shutil
 
 
 def counters(path, kernel_substr):
+    """Per-dispatch averages over the dispatches of the matching kernels -- the bench's launches only: a dispatch whose
+    grid is under 5 % of the largest matching one is something else (the 2,048-point accuracy probes of the multi-spec
+    path at the first Greeks step, which dragged the round-4 Greeks averages down by 10 % before this filter)."""
     files = glob.glob(os.path.join(path, "*counter_collection.csv"))
-    agg = collections.defaultdict(list)
+    rows = []
     for f in files:
         for r in csv.DictReader(open(f)):
             if kernel_substr in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                rows.append((r["Counter_Name"], float(r["Counter_Value"]), float(r.get("Grid_Size") or 0)))
+    gmax = max((g for _, _, g in rows), default=0.0)
+    agg = collections.defaultdict(list)
+    for name, val, g in rows:
+        if g >= 0.05 * gmax:
+            agg[name].append(val)
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
 
 
