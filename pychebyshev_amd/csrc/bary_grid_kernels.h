@@ -123,13 +123,17 @@ __device__ __forceinline__ void grid_weights_prod(double x, double scale, const 
 // 66 KB for 21^3, 122 KB for 40^3) left one or two workgroups per CU -- one or two waves per SIMD to hide an L2 round
 // trip per row tile and a prologue of ~1,500 vector instructions (measured: the pipe 56 % busy, each wave idle 73 % of
 // its life).  Here the table holds the TAIL dimensions only until the B operands are in registers and is then
-// overwritten by the HEAD dimensions: gp.trows = max(head rows + slack, tail rows + 1) rows, 11 KB for 21^3, 20 KB for
-// 40^3, so that 7-14 waves fit a CU.  dynamic LDS = WPB * gp.trows * PW * 8 bytes.  grid = (point blocks, chunk splits, specs).
+// overwritten by the HEAD dimensions -- without dimension A, whose weight is formed once per chunk (prologue 3):
+// gp.trows = max(outer rows + B rows + slack, tail rows + 1) + 2 rows, 7 KB for 21^3, 11 KB for 40^3, so that 14-22 waves fit a CU.  dynamic LDS = WPB * gp.trows * PW * 8 bytes.  grid = (point blocks, chunk splits, specs).
 // WPB = waves per workgroup: 1 for tensors whose fragment image sits in L2 (waves then come and go independently), 4 for
 // large ones (64^4: 134 MB) -- four waves started together walk the image in step, so a fragment fetched by one is an
 // L1 / L2 hit for the others (one wave per workgroup: 0.49 of the peak on 64^4, four: 0.69).
-template <int KS, int NT, int WPB>
-__global__ void __launch_bounds__(64 * WPB, WPB == 4 ? (KS * NT <= 34 ? 2 : 1) : ((KS * NT <= 20) ? 4 : ((KS * NT <= 34) ? 3 : 2)))
+// AF ("A formed"): dimension A's weight is formed once per chunk instead of being read from the table (prologue 3) -- for
+// chunks of >= 48 matrix-instruction pairs (32^3 ... 48^3, 64^4): half the table, twice the waves, one division per chunk;
+// shorter chunks (20^3 ... 30^3) keep A in the table (measured: 24^3 0.53 against 0.50 formed, 40^3 0.64 against 0.68).
+template <int KS, int NT, int WPB, bool AF>
+__global__ void __launch_bounds__(64 * WPB, WPB == 4 ? (KS * NT <= 34 ? 2 : 1)
+                                            : (AF ? ((KS * NT <= 10) ? 4 : ((KS * NT <= 24) ? 3 : 2)) : ((KS * NT <= 20) ? 4 : ((KS * NT <= 32) ? 3 : 2))))
 k_bary_mfma_grid(BaryDims dims, BaryMfmaPlan plan, BaryGridPlan gp, const double *__restrict__ nodes,
                  const double *__restrict__ wts, const double *__restrict__ snodes, const double *const *__restrict__ frag_tab,
                  const unsigned *__restrict__ kcode, const double *__restrict__ pts, double *__restrict__ out, long N,
@@ -185,17 +189,51 @@ k_bary_mfma_grid(BaryDims dims, BaryMfmaPlan plan, BaryGridPlan gp, const double
     }
     __syncthreads();
 
-    // ---- prologue 3: weights of the HEAD dimensions over the same rows; slack rows behind them are zero ----
+    // ---- prologue 3: weights of the HEAD dimensions over the same rows -- all but dimension A.  A's weight is needed once
+    // per chunk and lane group, so its table (as many rows as B's) would halve the waves per CU for nothing: of A only the
+    // reciprocal of S = sum_k w_k / (x - x_k) and the index of an exact node (-1: none) are kept per point, and
+    // b_A[i] = (w_i / (x - x_i)) (1 / S) is formed where it is used (one division per chunk, lane group and column tile).
+    // B sits where A's rows would be (gp.rowB); slack rows behind it are zero. ----
+    const int dimA = plan.split - 2;
+    double *srow = bw + (size_t)(gp.trows - 2) * PW, *erow = srow + PW;
     for (int k = ph; k < plan.split; k += PH) {
         const double *nd = nodes + dims.off[k];
         const double x = valid ? pts[prow * dims.d + k] : nd[0];
-        double *dst = bw + (size_t)dims.off[k] * PW + pp;
+        if (AF && k == dimA) {
+            const double *wk = wts + dims.off[k];
+            double su = 0.0;
+            int exact = -1;
+#pragma unroll 1
+            for (int j = 0; j < dims.n[k]; ++j) {
+                const double diff = x - nd[j];
+                if (exact < 0 && __builtin_fabs(diff) < 1e-14) exact = j;      // barycentric.py:1039-1043
+                su += wk[j] / diff;
+            }
+            srow[pp] = 1.0 / su;
+            erow[pp] = (double)exact;
+            continue;
+        }
+        double *dst = bw + (size_t)(k == plan.split - 1 ? gp.rowB : (k == dimA ? gp.rowA : dims.off[k])) * PW + pp;
         if (snodes) grid_weights_prod(x, snodes[dims.sum_n + k], snodes + dims.off[k], wts + dims.off[k], dims.n[k], dst, PW);
         else grid_weights_1d(x, nd, wts + dims.off[k], dims.n[k], dst, PW);
     }
     if (ph == 0)
-        for (int r = tail0; r < gp.hrows; ++r) bw[(size_t)r * PW + pp] = 0.0;
+        for (int r = gp.rowB + gp.nB; r < gp.hrows; ++r) bw[(size_t)r * PW + pp] = 0.0;
     __syncthreads();
+    double xA[NT], rS[NT];
+    int eA[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        xA[nt] = 0.0; rS[nt] = 0.0; eA[nt] = -1;
+        if constexpr (AF) {
+            const long pidx = base + 16 * nt + c;
+            const long rw = pidx < N ? (perm ? (long)perm[pidx] : pidx) : -1;
+            xA[nt] = rw >= 0 ? pts[rw * dims.d + dimA] : nodes[dims.off[dimA]];
+            rS[nt] = srow[16 * nt + c];
+            eA[nt] = (int)erow[16 * nt + c];
+        }
+    }
+    const double *nodeA = nodes + dims.off[dimA], *wtA = wts + dims.off[dimA];
 
     const int ga = g >> gp.gbs, gb = g & ((1 << gp.gbs) - 1);
     const int jstep = (PW << gp.gbs);                         // table rows GB apart, in doubles
@@ -223,6 +261,9 @@ k_bary_mfma_grid(BaryDims dims, BaryMfmaPlan plan, BaryGridPlan gp, const double
     for (int ch = ch0; ch < ch1; ++ch) {
         const int tA = ch % gp.TA;
         const int o = ch / gp.TA;
+        const int iA = tA * gp.RA + ga;                        // this lane group's A index; its node and weight are fetched now
+        double xA_i = 0.0, wA_i = 0.0;
+        if constexpr (AF) { xA_i = nodeA[iA < gp.nA ? iA : 0]; wA_i = wtA[iA < gp.nA ? iA : 0]; }
         double q[NT];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) q[nt] = 0.0;
@@ -256,10 +297,18 @@ k_bary_mfma_grid(BaryDims dims, BaryMfmaPlan plan, BaryGridPlan gp, const double
 #pragma unroll
                 for (int j = 0; j < 4; ++j) q[nt] = __builtin_fma(acc[nt][j], wb[nt][j], q[nt]);
         }
-        // chunk end: the A weight of this lane group, the outer weights of this chunk
+        // chunk end: the A weight of this lane group (formed here, see prologue 3), the outer weights of this chunk
         double wo[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) wo[nt] = colA[(size_t)tA * gp.RA * PW + 16 * nt];
+        for (int nt = 0; nt < NT; ++nt) {
+            if constexpr (AF) {
+                double b = (wA_i / (xA[nt] - xA_i)) * rS[nt];
+                if (eA[nt] >= 0) b = (iA == eA[nt]) ? 1.0 : 0.0;
+                wo[nt] = iA < gp.nA ? b : 0.0;
+            } else {
+                wo[nt] = colA[(size_t)tA * gp.RA * PW + 16 * nt];
+            }
+        }
         if (gp.nouter == 1) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) wo[nt] = colO0[(size_t)o * PW + 16 * nt] * wo[nt];

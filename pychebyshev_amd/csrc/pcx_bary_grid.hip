@@ -30,22 +30,26 @@ PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, Bar
     gp.nA = nA; gp.nB = nB;
     gp.TA = (nA + gp.RA - 1) / gp.RA;
     gp.TB = (nB + 16 / gp.RA - 1) / (16 / gp.RA);
-    gp.rowA = dm.off[split - 2]; gp.rowB = dm.off[split - 1];
+    gp.af = gp.TB * plan.KS >= 48 ? 1 : 0;                          // long chunks: A's weight formed per chunk, no table rows for A
+    gp.rowA = dm.off[split - 2];
+    gp.rowB = gp.af ? dm.off[split - 2] : dm.off[split - 1];
     gp.nouter = split - 2;
     gp.no1 = split == 4 ? dm.n[1] : 1;
     gp.rowo0 = dm.off[0]; gp.rowo1 = split == 4 ? dm.off[1] : 0;
     gp.nchunks = (int)(O * gp.TA);
     gp.MT = (int)best;
-    const int head_rows = dm.off[split], tail_rows = dm.sum_n - head_rows;
-    gp.hrows = std::max(head_rows, gp.rowB + gp.TB * (16 / gp.RA));
-    gp.trows = std::max(gp.hrows, tail_rows + 1);
+    const int tail_rows = dm.sum_n - dm.off[split];
+    gp.hrows = gp.rowB + gp.TB * (16 / gp.RA);                       // outer rows, (A rows,) B rows, zeroed slack of B's last tile
+    gp.trows = std::max(gp.hrows, tail_rows + 1) + 2;                // + 1 / S and the exact-node index of dimension A per point (af)
     gp.wpb = (size_t)gp.MT * plan.KS * 512 > ((size_t)1 << 20) ? 4 : 1;
-    // Measured (profiles/r04_bary_rate_probe.txt, fraction of the FP64 peak, row codes -> grid): 30^3 0.41 -> 0.48, 40^3
-    // 0.54 -> 0.61, 24^3 0.47 -> 0.50, 20^3 0.44 -> 0.49, 32^3 0.46 -> 0.55, 64^4 0.58 -> 0.69; 21^3 0.39 -> 0.39 (18 % more
-    // row tiles); and 65^3 0.61 -> 0.52-0.58: from 13 k-steps on the row-code kernel's hand-pipelined loop is ahead
-    // unless the grid pads nothing.
+    // Measured (profiles/r04_bary_rate_probe.txt, fraction of the FP64 peak, row codes -> grid): 30^3 0.41 -> 0.50, 40^3
+    // 0.54 -> 0.70, 48^3 0.76, 32^3 0.46 -> 0.60, 28^3 0.42 -> 0.56, 20^3 0.44 -> 0.48, 64^4 0.58 -> 0.84, 65^3 0.61 -> 0.74; 21^3
+    // 0.39 -> 0.39 (18 % more row tiles), 7^5 0.66 -> 0.56 (27 % more): from 13 k-steps on the row-code kernel's
+    // hand-pipelined loop stays ahead unless the grid pads little AND forms A's weight per chunk.
     const double cost_grid = (double)gp.MT * (plan.KS + 1.0), cost_codes = (double)plan.MT * (plan.KS + 5.0);
-    if (plan.KS > 12) return gp.MT == plan.MT;
+    static const bool force = [] { const char *e = getenv("PCX_BARY_GRID"); return e && e[0] == '2'; }();   // experiments: every eligible plan
+    if (force) return true;
+    if (plan.KS > 12) return gp.MT == plan.MT || (gp.af && gp.MT * 100L <= plan.MT * 112L);      // 65^3: 289 tiles for 265, 0.61 -> 0.74
     return cost_grid <= 0.85 * cost_codes;
 }
 
@@ -61,11 +65,11 @@ PCX_HIDDEN int bary_pack_grid(pcx_bary *h, const double *plain, double *frag) {
     return PCX_OK;
 }
 
-template <int KS, int NT, int WPB>
+template <int KS, int NT, int WPB, bool AF>
 static int launch_grid_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
                          long ostride, long ooff, hipStream_t st, Scratch *split_scratch, const int *perm) {
     const size_t lds = bary_grid_lds_bytes(h, NT);
-    auto kern = k_bary_mfma_grid<KS, NT, WPB>;
+    auto kern = k_bary_mfma_grid<KS, NT, WPB, AF>;
     if (lds > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     const long per_wg = 16L * NT * WPB;
@@ -102,13 +106,15 @@ template <int NT>
 static int launch_grid_nt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
                           long ostride, long ooff, hipStream_t st, Scratch *split_scratch, const int *perm) {
     switch (h->plan.KS) {
-#define CASE_KS(v) case v: return h->gp.wpb == 4 ? launch_grid_t<v, NT, 4>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm) \
-                                        : launch_grid_t<v, NT, 1>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+#define GRID_GO(v, W, A) launch_grid_t<v, NT, W, A>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm)
+#define CASE_KS(v) case v: return h->gp.wpb == 4 ? (h->gp.af ? GRID_GO(v, 4, true) : GRID_GO(v, 4, false)) \
+                                        : (h->gp.af ? GRID_GO(v, 1, true) : GRID_GO(v, 1, false));
         CASE_KS(1) CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8)
         CASE_KS(9) CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
         CASE_KS(17) CASE_KS(18) CASE_KS(19) CASE_KS(20) CASE_KS(21) CASE_KS(22) CASE_KS(23) CASE_KS(24)
         CASE_KS(25) CASE_KS(26) CASE_KS(27) CASE_KS(28) CASE_KS(29) CASE_KS(30) CASE_KS(31) CASE_KS(32)
 #undef CASE_KS
+#undef GRID_GO
     }
     return fail(PCX_ERR_UNSUPPORTED, "no grid MFMA instantiation for KS=%d", h->plan.KS);
 }

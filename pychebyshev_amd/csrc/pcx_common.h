@@ -51,6 +51,7 @@ struct BaryGridPlan {
     int nchunks;     // O * TA
     int hrows;       // head rows + the slack the padded B index of a last tile reads (zeroed)
     int trows;       // table rows per wave: max(hrows, tail rows + 1)
+    int af;          // 1: dimension A's weight is formed per chunk, the table has no rows for A (B sits at rowA)
     int wpb;         // waves per workgroup: 1 (fragment image in L2) or 4 (large tensors: the waves share the stream)
     int MT;          // nchunks * TB row tiles
 };
