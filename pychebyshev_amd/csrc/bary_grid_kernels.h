@@ -247,10 +247,13 @@ k_bary_mfma_grid(BaryDims dims, BaryMfmaPlan plan, BaryGridPlan gp, const double
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) total[nt] = 0.0;
 
-    // Fragment loads stay DEPTH k-steps ahead ACROSS tile boundaries (the first DEPTH fragments of tile t + 1 are fetched
-    // during the tail of tile t into `head`), as in k_bary_mfma's long-plan loop; for plans of up to 8 k-steps that is a
-    // whole tile ahead.  Fences keep hipcc from sinking the loads to their uses.
-    constexpr int DEPTH = KS < 8 ? KS : 8;
+    // Fragment loads stay DEPTH k-steps ahead ACROSS tile boundaries, as in k_bary_mfma's long-plan loop.  Plans of up to 12
+    // k-steps keep a WHOLE tile ahead: the register a k-step has just consumed is refilled with the same k-step's fragment
+    // of the next tile (no copies).  Longer plans run a ring of 8: the first 8 fragments of tile t + 1 are fetched during the
+    // tail of tile t into `head` and copied into the ring at the tile's start (the ring's phase would otherwise rotate by
+    // KS mod 8 per tile).  Fences keep hipcc from sinking the loads to their uses.
+    constexpr bool WHOLE = KS <= 12;
+    constexpr int DEPTH = WHOLE ? KS : 8;
     double head[DEPTH];
     const long t_first = (long)ch0 * gp.TB, t_last = (long)ch1 * gp.TB;
     if (t_first < t_last) {
@@ -279,18 +282,30 @@ k_bary_mfma_grid(BaryDims dims, BaryMfmaPlan plan, BaryGridPlan gp, const double
                 for (int j = 0; j < 4; ++j) wb[nt][j] = cb[16 * nt + j * jstep];
             const gptr_t tt = tf + (size_t)t * KS * 64;
             const gptr_t tn = tf + (size_t)(t + 1 < t_last ? t + 1 : t) * KS * 64;
-            double ring[DEPTH];
+            if constexpr (WHOLE) {
 #pragma unroll
-            for (int i = 0; i < DEPTH; ++i) ring[i] = head[i];
+                for (int s = 0; s < KS; ++s) {
+                    const double a = head[s];
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < KS; ++s) {
-                const double a = ring[s % DEPTH];
-                if (s + DEPTH < KS) ring[s % DEPTH] = tt[(s + DEPTH) * 64];
-                else head[s + DEPTH - KS] = tn[(s + DEPTH - KS) * 64];
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt][s], acc[nt], 0, 0, 0);
+                    head[s] = tn[s * 64];                   // the same k-step of the next tile, into the register just read
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                double ring[DEPTH];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt][s], acc[nt], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < DEPTH; ++i) ring[i] = head[i];
+#pragma unroll
+                for (int s = 0; s < KS; ++s) {
+                    const double a = ring[s % DEPTH];
+                    if (s + DEPTH < KS) ring[s % DEPTH] = tt[(s + DEPTH) * 64];
+                    else head[s + DEPTH - KS] = tn[(s + DEPTH - KS) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, B[nt][s], acc[nt], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
