@@ -100,10 +100,19 @@ def test_bench_single_rank_with_rccl_forced():
                    "--no-cpu-baseline"], {"PCX_BENCH_FORCE_COMM": "1"})
     assert line["n_gpus"] == 1 and line["config"]["gather"] == "rccl"
     assert line["comm"]["backend"] == "rccl" and line["comm"]["torch"] is False
-    for mode in ("none", "rccl", "rccl+d2h", "d2h"):
+    for mode in ("none", "rccl", "rccl+d2h", "d2h", "h2d+d2h"):
         assert line["gather"][mode]["value"] > 0
     assert line["gather"]["d2h"]["host_buffer_pinned"] is True
+    assert line["gather"]["h2d+d2h"]["points_page_locked"] is True
     assert 0 < line["roofline"]["frac"] < 1
+    # round 4: what every rank ran on, and every rank's block of the collected result verified
+    comm = line["comm"]
+    assert comm["world"] == 1 and comm["distinct_gpus"] == 1 and comm["rccl_world_seen_by_every_rank"] is True
+    rec = comm["ranks"][0]
+    assert rec["rank"] == 0 and rec["comm_world"] == 1 and rec["rccl_version"] > 0 and ":" in rec["pci_bus_id"]
+    assert line["config"]["blocks_verified"] == 1
+    for mode in ("rccl", "rccl+d2h", "d2h", "h2d+d2h"):
+        assert "block of every rank (1)" in line["gather"][mode]["blocks_verified"]
 
 
 def test_bench_goes_on_when_the_rccl_bootstrap_misses_its_deadline():
@@ -125,6 +134,12 @@ def test_bench_launches_two_ranks_itself():
     assert len(line["roofline"]["avg_launch_ms_per_rank"]) == 2
     assert line["gather"]["none"]["value"] > 0 and line["gather"]["d2h"]["value"] > 0
     assert "cpu_baseline" not in line                       # rank 0 at N = 1 only
+    # round 4: one record per rank (both on GPU 0 here: one distinct bus id), both blocks verified, the host-to-host leg
+    ranks = line["comm"]["ranks"]
+    assert [r["rank"] for r in ranks] == [0, 1] and len({r["pid"] for r in ranks}) == 2
+    assert line["comm"]["distinct_gpus"] == 1 and line["comm"]["world"] == 2
+    assert line["config"]["blocks_verified"] == 2
+    assert line["gather"]["h2d+d2h"]["value"] > 0 and "block of every rank (2)" in line["gather"]["h2d+d2h"]["blocks_verified"]
 
 
 def test_bench_under_the_driver_launcher():

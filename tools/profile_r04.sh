@@ -29,5 +29,9 @@ PY
 python3 bench.py > gpurun_out/r04/bench_bary5d.json 2> gpurun_out/r04/bench_bary5d.err || echo "bench failed"
 for wl in bary5d greeks5d tt5d tt10d; do cp gpurun_out/prof_$wl/r04_${wl}_summary.json profiles/ 2>/dev/null; done
 cp gpurun_out/r04/bench_bary5d.json profiles/r04_bench_bary5d.json
+# the multi-rank step as far as a one-GPU box can take it: RCCL with one rank; two ranks on GPU 0 (shared-memory collection)
+PCX_BENCH_FORCE_COMM=1 python3 bench.py --no-companion --no-cpu-baseline > profiles/r04_bench_bary5d_rccl_1rank.json 2> gpurun_out/r04/bench_rccl_1rank.err || echo "rccl 1-rank bench failed"
+PCX_BENCH_SHARE_DEVICE=1 python3 bench.py --gpus 2 --no-companion > profiles/r04_bench_bary5d_2ranks_one_gpu.json 2> gpurun_out/r04/bench_2ranks.err || echo "2-rank bench failed"
+cp profiles/r04_bench_bary5d_rccl_1rank.json profiles/r04_bench_bary5d_2ranks_one_gpu.json gpurun_out/r04/ 2>/dev/null
 python3 tools/check_profiles_vs_bench.py --round r04 --bench gpurun_out/r04/bench_bary5d.json > gpurun_out/r04/check.txt 2>&1
 cat gpurun_out/r04/check.txt
