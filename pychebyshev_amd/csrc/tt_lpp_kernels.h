@@ -127,7 +127,11 @@ k_tt_eval_lpp(const TTLppDim *__restrict__ tab, int d, const double *__restrict_
     const tab_cptr ct = (tab_cptr)(unsigned long long)tab;
     const pcx_lpp_cptr cimg = (pcx_lpp_cptr)(unsigned long long)img;
     const long p = (long)blockIdx.x * PCX_LPP_WG + threadIdx.x;
+#ifdef PCX_LPP_LAB_WRAP      // tools/tt_w4_lab.hip only: every wave reads the same 1,024 rows and stores nothing beyond them (no HBM traffic)
+    const long pc = p & 1023;
+#else
     const long pc = p < N ? p : N - 1;
+#endif
     double xn = pts[pc * d + ct[0].col];
     vl[0] = 1.0;                                   // v of the (rank-1) left boundary
     for (int k = 0; k < d; ++k) {
@@ -159,5 +163,9 @@ k_tt_eval_lpp(const TTLppDim *__restrict__ tab, int d, const double *__restrict_
             }
         }
     }
+#ifdef PCX_LPP_LAB_WRAP
+    if (p < 1024) out[p] = vl[0];
+#else
     if (p < N) out[p] = vl[0];
+#endif
 }
