@@ -291,3 +291,34 @@ def test_spline_with_equal_trailing_node_counts_runs_on_the_sq_kernel(monkeypatc
                  sp.eval_batch(pts[:1], specs[0])]
     for a, b in zip(fused, per_piece):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.gpu
+def test_spline_pieces_on_the_grid_mfma_kernel(oracle_mod):
+    """Round 4: pieces of 20 x 20 x 20 nodes run on k_bary_mfma_grid through the bucket permutation (`perm` argument):
+    two pieces, one of them with a third of the points, value and two derivative specs, a small and a large batch."""
+    import math
+    f = lambda x, _=None: math.sin(1.3 * x[0]) * math.cos(0.7 * x[1]) + abs(x[0] - 0.2) * (1.0 + 0.1 * x[2]) + x[1] * x[2]
+    dom = [[-1.0, 1.0], [0.0, 2.0], [-0.5, 0.5]]
+    sp = ChebyshevSpline(f, 3, dom, n_nodes=[20, 20, 20], knots=[[0.2], [], []])
+    sp.build(verbose=False)
+    assert len(sp._pieces) == 2
+    for pc in sp._pieces:
+        m = pc._model()
+        gi = _lib.i32(np.zeros(4))
+        assert m.lib.pcx_bary_grid_info(m.handle, _lib.p_i32(gi)) == 0 and gi[0] == 1
+        info = _lib.i32(np.zeros(6))
+        m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
+        assert info[0] == 2                                      # auto: the MFMA (grid) kernel for 20^3
+    rng = np.random.default_rng(44)
+    pts = np.column_stack([rng.uniform(lo, hi, 150_000) for lo, hi in dom])
+    models = [oracle_mod.BaryModel(p.nodes, p.weights, p.diff_matrices, p.tensor_values) for p in sp._pieces]
+    sub = rng.choice(len(pts), 4000, replace=False)
+    for spec in ([0, 0, 0], [1, 0, 0], [0, 1, 1]):
+        y = sp.eval_batch(pts, spec)
+        ref = oracle_mod.spline_eval_batch(models, sp.knots, sp._shape, pts[sub], spec)
+        assert_parity(y[sub], ref, 1e-12, f"grid spline {spec}", spec_point_tol(spec))
+        small = sp.eval_batch(pts[:999], spec)
+        assert np.array_equal(small, y[:999])                   # a point's value does not depend on its batch or bucket
+    multi = sp.eval_multi_batch(pts[:5000], [[0, 0, 0], [0, 0, 1]])
+    assert np.array_equal(multi[:, 0], sp.eval_batch(pts[:5000], [0, 0, 0]))
