@@ -125,15 +125,14 @@ __device__ __forceinline__ void grid_weights_prod(double x, double scale, const 
 // its life).  Here the table holds the TAIL dimensions only until the B operands are in registers and is then
 // overwritten by the HEAD dimensions -- without dimension A, whose weight is formed once per chunk (prologue 3):
 // gp.trows = max(outer rows + B rows + slack, tail rows + 1) + 2 rows, 7 KB for 21^3, 11 KB for 40^3, so that 14-22 waves fit a CU.  dynamic LDS = WPB * gp.trows * PW * 8 bytes.  grid = (point blocks, chunk splits, specs).
-// WPB = waves per workgroup: 1 for tensors whose fragment image sits in L2 (waves then come and go independently), 4 for
-// large ones (64^4: 134 MB) -- four waves started together walk the image in step, so a fragment fetched by one is an
-// L1 / L2 hit for the others (one wave per workgroup: 0.49 of the peak on 64^4, four: 0.69).
+// WPB = waves per workgroup: 4 wherever two such workgroups fit a CU -- four waves started together walk the fragment image
+// in step, so a fragment fetched by one is an L1 hit for the others (with one wave per workgroup every fragment load of every
+// wave misses L1: 64^4 0.49 of the peak against 0.76, 30^3 0.50 against 0.54) --, 1 when the table is too large for that.
 // AF ("A formed"): dimension A's weight is formed once per chunk instead of being read from the table (prologue 3) -- for
 // chunks of >= 48 matrix-instruction pairs (32^3 ... 48^3, 64^4): half the table, twice the waves, one division per chunk;
 // shorter chunks (20^3 ... 30^3) keep A in the table (measured: 24^3 0.53 against 0.50 formed, 40^3 0.64 against 0.68).
 template <int KS, int NT, int WPB, bool AF>
-__global__ void __launch_bounds__(64 * WPB, WPB == 4 ? (KS * NT <= 34 ? 2 : 1)
-                                            : (AF ? ((KS * NT <= 10) ? 4 : ((KS * NT <= 24) ? 3 : 2)) : ((KS * NT <= 20) ? 4 : ((KS * NT <= 32) ? 3 : 2))))
+__global__ void __launch_bounds__(64 * WPB, AF ? ((KS * NT <= 10) ? 4 : ((KS * NT <= 24) ? 3 : 2)) : ((KS * NT <= 20) ? 4 : ((KS * NT <= 32) ? 3 : 2)))
 k_bary_mfma_grid(BaryDims dims, BaryMfmaPlan plan, BaryGridPlan gp, const double *__restrict__ nodes,
                  const double *__restrict__ wts, const double *__restrict__ snodes, const double *const *__restrict__ frag_tab,
                  const unsigned *__restrict__ kcode, const double *__restrict__ pts, double *__restrict__ out, long N,

@@ -224,10 +224,10 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
                 // 21 and 23 nodes: hipcc runs out of scalar registers on the odd row length (SGPR spills in the block,
                 // 0.37 / 0.36 of the peak against 0.39 / 0.44 on the MFMA kernel): available, not preferred
                 // 26 / 28 / 30 nodes: ahead in 2-D (26^2 0.40 against 0.21), behind the MFMA kernel in 3-D (30^3 0.32 against 0.42)
-                // round 4 (k_bary_mfma_grid): 20^3 0.45 -> 0.49 and 32^3 0.48 -> 0.55 on the MFMA kernel; 24^3 stays (0.54 vs 0.50)
+                // round 4 (k_bary_mfma_grid): 20^3 0.45 -> 0.48, 24^3 0.545 -> 0.56, 32^3 0.48 -> 0.63 on the MFMA kernel
                 // (21 nodes: 0.44 here against 0.40 on the grid MFMA kernel -- preferred again; 23: 0.465 against 0.47)
                 h->sq_preferred = sq_auto && (d <= 3 || total <= kSmallTensorElems) && nl != 23 &&
-                                  !(d >= 3 && nl > 24) && !(d == 3 && nl == 20 && n_nodes[0] == 20);
+                                  !(d >= 3 && nl >= 24) && !(d == 3 && nl == 20 && n_nodes[0] == 20);      // 24^3: grid 0.56, here 0.545
             }
             // 2^e ~ 2 / (node span): exact to apply, keeps the prefix / suffix products of the weights in range
             std::vector<double> sn((size_t)sum_n);

@@ -41,7 +41,13 @@ PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, Bar
     const int tail_rows = dm.sum_n - dm.off[split];
     gp.hrows = gp.rowB + gp.TB * (16 / gp.RA);                       // outer rows, (A rows,) B rows, zeroed slack of B's last tile
     gp.trows = std::max(gp.hrows, tail_rows + 1) + 2;                // + 1 / S and the exact-node index of dimension A per point (af)
-    gp.wpb = (size_t)gp.MT * plan.KS * 512 > ((size_t)1 << 20) ? 4 : 1;
+    // Four waves per workgroup wherever two such workgroups fit a CU (or the image is beyond L2 anyway): waves started
+    // together walk the fragment image in step, so one wave's L2 fetch is an L1 hit for the other three.  With one wave per
+    // workgroup every fragment load of every wave misses L1 (TCP_PENDING_STALL_CYCLES: half the kernel's cycles on 30^3;
+    // measured 30^3 0.50 -> 0.54, 20^3 / 48^3 +3 %, the rest +1 %).
+    const size_t table = (size_t)gp.trows * 32 * sizeof(double);
+    gp.wpb = ((size_t)gp.MT * plan.KS * 512 > ((size_t)1 << 20) || 4 * table <= 80 * 1024) ? 4 : 1;
+
     // Measured (profiles/r04_bary_rate_probe.txt, fraction of the FP64 peak, row codes -> grid): 30^3 0.41 -> 0.50, 40^3
     // 0.54 -> 0.70, 48^3 0.76, 32^3 0.46 -> 0.60, 28^3 0.42 -> 0.56, 20^3 0.44 -> 0.48, 64^4 0.58 -> 0.84, 65^3 0.61 -> 0.74; 21^3
     // 0.39 -> 0.39 (18 % more row tiles), 7^5 0.66 -> 0.56 (27 % more): from 13 k-steps on the row-code kernel's

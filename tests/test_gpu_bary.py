@@ -825,7 +825,7 @@ def test_lane_per_point_kernel_for_small_tensors(oracle_mod, shape):
     m = c._model()
     m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
     sq = (d >= 2 and shape[-1] == shape[-2] and (4 <= shape[-1] <= 24 or shape[-1] in (26, 28, 30, 32)) and (d <= 3 or T.size <= 4096)
-          and shape[-1] != 23 and not (d >= 3 and shape[-1] in (26, 28, 30, 32)) and shape != (20, 20, 20))
+          and shape[-1] != 23 and not (d >= 3 and shape[-1] in (24, 26, 28, 30, 32)) and shape != (20, 20, 20))
     assert info[0] == (5 if sq else (4 if (T.size <= 4096 and shape[-1] <= 48) else 2))
     specs = [[0] * d]
     if all(v > 2 for v in shape):
