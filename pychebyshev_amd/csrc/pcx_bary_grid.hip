@@ -48,9 +48,9 @@ PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, Bar
     const size_t table = (size_t)gp.trows * 32 * sizeof(double);
     gp.wpb = ((size_t)gp.MT * plan.KS * 512 > ((size_t)1 << 20) || 4 * table <= 80 * 1024) ? 4 : 1;
 
-    // Measured (profiles/r04_bary_rate_probe.txt, fraction of the FP64 peak, row codes -> grid): 30^3 0.41 -> 0.50, 40^3
-    // 0.54 -> 0.70, 48^3 0.76, 32^3 0.46 -> 0.60, 28^3 0.42 -> 0.56, 20^3 0.44 -> 0.48, 64^4 0.58 -> 0.84, 65^3 0.61 -> 0.74; 21^3
-    // 0.39 -> 0.39 (18 % more row tiles), 7^5 0.66 -> 0.56 (27 % more): from 13 k-steps on the row-code kernel's
+    // Measured (profiles/r04_bary_rate_probe.txt, fraction of the FP64 peak, row codes -> grid): 30^3 0.41 -> 0.55, 40^3
+    // 0.54 -> 0.71, 48^3 0.78, 32^3 0.46 -> 0.64, 28^3 0.42 -> 0.58, 20^3 0.44 -> 0.49, 64^4 0.58 -> 0.84, 65^3 0.61 -> 0.74; 21^3
+    // 0.39 -> 0.41 (18 % more row tiles), 7^5 0.66 -> 0.56 (27 % more): from 13 k-steps on the row-code kernel's
     // hand-pipelined loop stays ahead unless the grid pads little AND forms A's weight per chunk.
     const double cost_grid = (double)gp.MT * (plan.KS + 1.0), cost_codes = (double)plan.MT * (plan.KS + 5.0);
     static const bool force = [] { const char *e = getenv("PCX_BARY_GRID"); return e && e[0] == '2'; }();   // experiments: every eligible plan
