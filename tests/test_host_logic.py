@@ -426,6 +426,56 @@ def test_accessor_surface_of_all_four_classes():
     assert sl.clone().pivot_point == [0.1, 0.2, 0.3] and sl.clone().function is None
 
 
+def test_device_array_pool_reuses_and_releases_blocks(monkeypatch):
+    """Result arrays of the device-resident methods come from a size-keyed pool (device.py): a dropped block is handed
+    out again for the same size, the cache is capped (PCX_DEVICE_POOL_MB), trim_pool() frees it, and a failing allocation
+    trims the cache and retries.  A stub stands in for the library: no device needed."""
+    import ctypes
+    from pychebyshev_amd import device as D
+
+    class Stub:
+        def __init__(self):
+            self.next, self.live, self.fail_once = 0x1000, set(), False
+        def pcx_dev_malloc(self, dev, nbytes, out):
+            if self.fail_once:
+                self.fail_once = False
+                return _lib.PCX_ERR_HIP
+            self.next += 0x1000
+            self.live.add(self.next)
+            ctypes.cast(out, ctypes.POINTER(ctypes.c_void_p))[0] = self.next
+            return 0
+        def pcx_dev_free(self, dev, ptr):
+            self.live.discard(ptr.value)
+            return 0
+        def pcx_last_error(self):
+            return b"stub"
+    stub = Stub()
+    monkeypatch.setattr(_lib, "load", lambda path=None: stub)
+    monkeypatch.setattr(D, "_POOL", {})
+    monkeypatch.setattr(D, "_POOL_BYTES", [0])
+    monkeypatch.setenv("PCX_DEVICE_POOL_MB", "1")
+    a = D.DeviceArray.empty((1000,), 0)
+    pa = a.ptr
+    del a                                                   # back to the pool, not freed
+    assert pa in stub.live and D._POOL_BYTES[0] == 8000
+    b = D.DeviceArray.empty((1000,), 0)
+    assert b.ptr == pa and D._POOL_BYTES[0] == 0           # the same block again
+    c = D.DeviceArray.empty((500, 2), 0)                    # same byte count, block in use: a new one
+    assert c.ptr != pa
+    big = D.DeviceArray.empty((200_000,), 0)                # 1.6 MB > the 1 MB cap: freed at once
+    pbig = big.ptr
+    del big
+    assert pbig not in stub.live
+    del b, c
+    assert D._POOL_BYTES[0] == 16000 and len(stub.live) == 2
+    stub.fail_once = True                                   # an allocation that fails while blocks are cached: trim, retry
+    d = D.DeviceArray.empty((77,), 0)
+    assert d.ptr and D._POOL_BYTES[0] == 0 and stub.live == {d.ptr}
+    del d
+    D.trim_pool()
+    assert not stub.live and D._POOL == {}
+
+
 def test_device_array_protocol_helpers_without_a_gpu():
     """The `__cuda_array_interface__` plumbing that needs no device: what counts as a device array, the
     C-contiguity rule, the dtype rule (pychebyshev_amd/device.py)."""
