@@ -22,7 +22,8 @@ HOST_H = ["pcx_common.h", "pcx_internal.h", PCX_H]
 SOURCES = {
     "pcx_core.hip": HOST_H,
     "pcx_bary.hip": HOST_H + ["pcx_bary_internal.h", "bary_kernels.h", "gather_kernels.h"],
-    "pcx_bary_grid.hip": HOST_H + ["pcx_bary_internal.h", "bary_grid_kernels.h"],
+    "pcx_bary_grid.hip": HOST_H + ["pcx_bary_internal.h", "bary_grid_kernels.h", "bary_weights.h"],
+    "pcx_bary_kfold.hip": HOST_H + ["pcx_bary_internal.h", "bary_kfold_kernels.h"],
     "pcx_spline.hip": HOST_H + ["pcx_bary_internal.h", "gather_kernels.h", "route_kernels.h"],
     "pcx_tt.hip": HOST_H + ["tt_kernels.h", "tt_lpp_kernels.h", "tt_fd_kernels.h"],
     "pcx_ttbuild.hip": HOST_H + ["ttcross_kernels.h", "ttsvd_kernels.h"],

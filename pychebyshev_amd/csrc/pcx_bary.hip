@@ -105,11 +105,13 @@ extern "C" int pcx_bary_destroy(pcx_bary *h) {
 static int bary_pack(pcx_bary *h, DerivedTensor &dt) {
     if (!h->mfma_ok) return PCX_OK;
     const BaryMfmaPlan &p = h->plan;
-    size_t cnt = (size_t)(h->grid_ok ? h->gp.MT : p.MT) * p.KS * 64;
+    size_t cnt = h->kfold_ok ? bary_kfold_frag_count(h->kf) : (size_t)(h->grid_ok ? h->gp.MT : p.MT) * p.KS * 64;
     DevBuf frag, slot;
     int rc = frag.alloc(cnt * sizeof(double));
     if (rc) return rc;
-    if (h->grid_ok) {
+    if (h->kfold_ok) {
+        if ((rc = bary_pack_kfold(h, dt.plain, frag.as<double>()))) return rc;
+    } else if (h->grid_ok) {
         if ((rc = bary_pack_grid(h, dt.plain, frag.as<double>()))) return rc;
     } else {
         int blocks = (int)((cnt + 255) / 256);
@@ -341,34 +343,41 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     // short plans: the grid form (bary_grid_kernels.h) -- unless the shape can share GEMMs between specs one order apart
     // (dim-0 groups above), which needs the slab packing of the row-code form
     if (h->mfma_ok && !h->g0_ok && !(h->plan.split > PCX_CODE_FIELDS || d - h->plan.split > PCX_CODE_FIELDS)) {
-        h->grid_ok = bary_plan_grid(h->dims, h->plan, h->gp);
+        // 3-D tensors whose first dimension fills whole row tiles: the k-fold form (bary_kfold_kernels.h) ahead of the grid form
+        h->kfold_ok = bary_plan_kfold(h->dims, h->kf);
+        if (h->kfold_ok) {
+            h->nt = 2;
+            if (bary_kfold_lds_bytes(h->kf, 2) > (size_t)72 * 1024) h->nt = 1;      // two workgroups per CU
+            if (bary_kfold_lds_bytes(h->kf, h->nt) > (size_t)150 * 1024) h->kfold_ok = false;   // a very long middle dimension
+        }
+        if (!h->kfold_ok) h->grid_ok = bary_plan_grid(h->dims, h->plan, h->gp);
         if (h->grid_ok) {
             h->nt = h->plan.KS > 32 ? 1 : 2;                       // the table is per wave and holds one part at a time
             const size_t cap = (size_t)(h->gp.wpb == 4 ? 150 : 64) * 1024;
             if (bary_grid_lds_bytes(h, h->nt) > cap) h->nt = 1;
             if (bary_grid_lds_bytes(h, h->nt) > cap) h->grid_ok = false;
         }
-        if (h->grid_ok) {
-            // division-free weights (as k_bary_small, bary_kernels.h): nodes scaled by 2^e ~ 2 / span per dimension
-            std::vector<double> sn((size_t)sum_n + PCX_MAX_DIMS, 0.0);
-            h->grid_prod = true;
-            for (int k = 0; k < d; ++k) {
-                const double *nd = nodes_cat + h->dims.off[k];
-                const double span = nd[n_nodes[k] - 1] - nd[0];
-                int e = 0;
-                if (span > 0.0 && std::isfinite(span)) (void)std::frexp(2.0 / span, &e);
-                const double sck = std::ldexp(1.0, e - 1);
-                sn[(size_t)sum_n + k] = sck;
-                for (int j = 0; j < n_nodes[k]; ++j) sn[h->dims.off[k] + j] = nd[j] * sck;
-                if (n_nodes[k] > 64) h->grid_prod = false;
-            }
-            static const bool prod_on = [] { const char *e = getenv("PCX_BARY_GRID_PROD"); return !(e && e[0] == '0'); }();
-            h->grid_prod = h->grid_prod && prod_on;
-            CREATE_TRY(hipMalloc((void **)&h->d_gsnodes, sn.size() * sizeof(double)));
-            CREATE_TRY(hipMemcpy(h->d_gsnodes, sn.data(), sn.size() * sizeof(double), hipMemcpyHostToDevice));
-        }
     }
-    if (h->grid_ok) h->mfma4_ok = false;
+    if (h->grid_ok || h->kfold_ok) {
+        // division-free weights for the grid and k-fold forms (bary_weights.h; as k_bary_small): nodes scaled by 2^e ~ 2 / span
+        // per dimension; PCX_BARY_GRID_PROD=0 (read per handle) keeps the weights by division (A/B measurements)
+        std::vector<double> sn((size_t)sum_n + PCX_MAX_DIMS, 0.0);
+        h->grid_prod = true;
+        for (int k = 0; k < d; ++k) {
+            const double *nd = nodes_cat + h->dims.off[k];
+            const double span = nd[n_nodes[k] - 1] - nd[0];
+            int e = 0;
+            if (span > 0.0 && std::isfinite(span)) (void)std::frexp(2.0 / span, &e);
+            const double sck = std::ldexp(1.0, e - 1);
+            sn[(size_t)sum_n + k] = sck;
+            for (int j = 0; j < n_nodes[k]; ++j) sn[h->dims.off[k] + j] = nd[j] * sck;
+            if (n_nodes[k] > 64) h->grid_prod = false;
+        }
+        { const char *e = getenv("PCX_BARY_GRID_PROD"); if (e && e[0] == '0') h->grid_prod = false; }
+        CREATE_TRY(hipMalloc((void **)&h->d_gsnodes, sn.size() * sizeof(double)));
+        CREATE_TRY(hipMemcpy(h->d_gsnodes, sn.data(), sn.size() * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (h->grid_ok || h->kfold_ok) h->mfma4_ok = false;
 
     // value tensor (derivative spec all-zero) enters the cache at create
     DerivedTensor dt;
@@ -861,6 +870,7 @@ PCX_HIDDEN int bary_launch(pcx_bary *h, DerivedTensor *const *dts, int m, const 
     }
     if (variant == 2) {
         if (!h->mfma_ok) return fail(PCX_ERR_UNSUPPORTED, "MFMA kernel does not cover this shape");
+        if (h->kfold_ok) return bary_launch_kfold(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
         if (h->grid_ok) return bary_launch_grid(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
         // two column tiles per wave for throughput; one when the batch cannot fill the chip
         int nt = (N >= 65536) ? h->nt : 1;
@@ -1575,9 +1585,11 @@ extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
     PCX_API_BEGIN
     if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
     { const int keep = h->variant; h->variant = 0; info[0] = bary_effective_variant(h); h->variant = keep; }
-    info[1] = h->mfma_ok ? (h->grid_ok ? h->gp.MT : h->plan.MT) : 0;
-    info[2] = h->mfma_ok ? h->plan.KS : 0;
-    info[3] = h->mfma_ok ? (int32_t)mfma_lds_bytes(h->dims, h->nt) : (256 / h->lpp) * h->dims.sum_n * 8;
+    info[1] = h->mfma_ok ? (h->kfold_ok ? h->kf.MT : (h->grid_ok ? h->gp.MT : h->plan.MT)) : 0;
+    info[2] = h->mfma_ok ? (h->kfold_ok ? h->kf.n1 * h->kf.KS2 : h->plan.KS) : 0;
+    info[3] = h->mfma_ok ? (int32_t)(h->kfold_ok ? bary_kfold_lds_bytes(h->kf, h->nt)
+                                                  : (h->grid_ok ? bary_grid_lds_bytes(h, h->nt) : mfma_lds_bytes(h->dims, h->nt)))
+                         : (256 / h->lpp) * h->dims.sum_n * 8;
     info[4] = h->mfma_ok ? 64 * h->nt : 256 / h->lpp;
     info[5] = h->mfma_ok ? h->plan.split : h->dims.d - 1;
     return PCX_OK;
@@ -1587,10 +1599,10 @@ extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
 extern "C" int pcx_bary_grid_info(pcx_bary *h, int32_t *info) {
     PCX_API_BEGIN
     if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
-    info[0] = h->grid_ok ? 1 : 0;
+    info[0] = h->grid_ok ? 1 : (h->kfold_ok ? 2 : 0);
     info[1] = h->grid_ok ? h->gp.RA : 0;
-    info[2] = h->grid_ok ? h->gp.MT : 0;
-    info[3] = h->grid_ok ? h->gp.nchunks : 0;
+    info[2] = h->grid_ok ? h->gp.MT : (h->kfold_ok ? h->kf.MT : 0);
+    info[3] = h->grid_ok ? h->gp.nchunks : (h->kfold_ok ? h->kf.KS2 : 0);
     return PCX_OK;
     PCX_API_END
 }

@@ -9,8 +9,8 @@
 // here (four FMAs on four table rows at fixed strides).  The grid pads dimension A to RA and B to 16 / RA rows per tile:
 // RA is chosen for the fewest tiles.  A margin of 8 % keeps the long plans (11^5: 31 k-steps) where they are.
 PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, BaryGridPlan &gp) {
-    static const bool enabled = [] { const char *e = getenv("PCX_BARY_GRID"); return !(e && e[0] == '0'); }();
-    if (!enabled) return false;
+    const char *env = getenv("PCX_BARY_GRID");                      // read per handle: a process may build both forms (tests)
+    if (env && env[0] == '0') return false;
     const int split = plan.split;
     if (split < 2 || split > 4 || dm.d - split > PCX_CODE_FIELDS || plan.KS > 32) return false;
     const int nA = dm.n[split - 2], nB = dm.n[split - 1];
@@ -53,8 +53,7 @@ PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, Bar
     // 0.39 -> 0.41 (18 % more row tiles), 7^5 0.66 -> 0.56 (27 % more): from 13 k-steps on the row-code kernel's
     // hand-pipelined loop stays ahead unless the grid pads little AND forms A's weight per chunk.
     const double cost_grid = (double)gp.MT * (plan.KS + 1.0), cost_codes = (double)plan.MT * (plan.KS + 5.0);
-    static const bool force = [] { const char *e = getenv("PCX_BARY_GRID"); return e && e[0] == '2'; }();   // experiments: every eligible plan
-    if (force) return true;
+    if (env && env[0] == '2') return true;                          // experiments: every eligible plan
     if (plan.KS > 12) return gp.MT == plan.MT || (gp.af && gp.MT * 100L <= plan.MT * 112L);      // 65^3: 289 tiles for 265, 0.61 -> 0.74
     return cost_grid <= 0.85 * cost_codes;
 }

@@ -50,6 +50,8 @@ struct pcx_bary {
     bool grid_ok = false;
     BaryGridPlan gp;
     double *d_gsnodes = nullptr;     // nodes times a power of two per dimension, then the PCX_MAX_DIMS scales themselves
+    bool kfold_ok = false;           // 3-D, whole row tiles along dimension 0: k_bary_mfma_kfold (bary_kfold_kernels.h)
+    BaryKfoldPlan kf;
     bool grid_prod = false;          // every dimension <= 64 nodes: division-free weights (grid_weights_prod)
     // dim-0 groups (BaryG0): specs differing only in their dim-0 order share one slab-packed GEMM
     bool g0_ok = false;
@@ -95,6 +97,12 @@ static const int kMaxSpecs = 64;      // derivative specs evaluated by one launc
 PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, BaryGridPlan &gp);
 PCX_HIDDEN int bary_pack_grid(pcx_bary *h, const double *plain, double *frag);
 PCX_HIDDEN size_t bary_grid_lds_bytes(const pcx_bary *h, int nt);
+PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp);
+PCX_HIDDEN size_t bary_kfold_frag_count(const BaryKfoldPlan &kp);
+PCX_HIDDEN size_t bary_kfold_lds_bytes(const BaryKfoldPlan &kp, int nt);
+PCX_HIDDEN int bary_pack_kfold(pcx_bary *h, const double *plain, double *frag);
+PCX_HIDDEN int bary_launch_kfold(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
+                                 long ostride, long ooff, hipStream_t st, const int *perm);
 PCX_HIDDEN int bary_launch_grid(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
                                 long ostride, long ooff, hipStream_t st, Scratch *split_scratch, const int *perm);
 

@@ -1,0 +1,91 @@
+// pcx_bary_kfold.hip -- planning, packing and launching of k_bary_mfma_kfold (bary_kfold_kernels.h): the MFMA form for
+// 3-D tensors whose first dimension fills whole row tiles.  Part of the barycentric handle (pcx_bary.hip).
+
+#include "pcx_bary_internal.h"
+#include "bary_kfold_kernels.h"
+
+// Eligible: three dimensions, n0 <= 64 (four row tiles in the accumulators), n2 <= 64 (sixteen B operands of dimension 2 in
+// registers), at least 8 fragments per i1 (the prefetch ring), and little padding: the share n0 / (16 MT) x n2 / (4 KS2) of
+// real products must be at least 0.85 (30^3: 0.88, 32^3 / 48^3 / 64^3: 1.0) -- above 0.75 for one or two row tiles, where
+// the grid form's short tiles cost more than the padding: measured with PCX_BARY_KFOLD_EFF=50 against the shipped rule
+// (profiles/r04_bary_rate_probe_kfold50.txt) 26^3 0.556 / 0.472 (grid), 29^3 0.615 / 0.498, 24^3 0.552 / 0.556, 23^3 0.497 / 0.493,
+// 20^3 0.444 / 0.484, 36^3 0.614 / 0.649, 40^3 0.676 / 0.691, 52^3 0.724 / 0.767.  PCX_BARY_KFOLD=0 switches the form off,
+// PCX_BARY_KFOLD_EFF=<percent> replaces both bars (experiments).
+PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp) {
+    const char *env = getenv("PCX_BARY_KFOLD"), *eff = getenv("PCX_BARY_KFOLD_EFF");    // read per handle
+    int bar = eff ? atoi(eff) : 0;
+    if (bar <= 0 || bar > 100) bar = 0;
+    if ((env && env[0] == '0') || dm.d != 3) return false;
+    kp.n0 = dm.n[0]; kp.n1 = dm.n[1]; kp.n2 = dm.n[2];
+    if (kp.n0 > 64 || kp.n2 > 64 || kp.n2 < 2) return false;
+    kp.MT = (kp.n0 + 15) / 16;
+    kp.KS2 = (kp.n2 + 3) / 4;
+    if (kp.MT * kp.KS2 < 8) return false;
+    kp.trows = std::max(std::max(16 * kp.MT, kp.n1), 4 * kp.KS2);
+    const long used = (long)kp.n0 * kp.n2, padded = 64L * kp.MT * kp.KS2;
+    if (bar) return used * 100 >= padded * bar;
+    return kp.MT <= 2 ? used * 100 > padded * 75 : used * 100 >= padded * 85;
+}
+
+PCX_HIDDEN size_t bary_kfold_frag_count(const BaryKfoldPlan &kp) {
+    return ((size_t)kp.n1 * kp.KS2 * kp.MT + PCX_KFOLD_PAD) * 64;
+}
+
+PCX_HIDDEN size_t bary_kfold_lds_bytes(const BaryKfoldPlan &kp, int nt) {       // per workgroup of four waves
+    return (size_t)4 * kp.trows * 16 * nt * sizeof(double);
+}
+
+PCX_HIDDEN int bary_pack_kfold(pcx_bary *h, const double *plain, double *frag) {
+    const size_t cnt = bary_kfold_frag_count(h->kf);
+    hipLaunchKernelGGL(k_pack_fragments_kfold, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, h->stream, plain, frag, h->kf);
+    HIP_TRY(hipGetLastError());
+    return PCX_OK;
+}
+
+template <int MT, int KS2, int NT>
+static int launch_kfold_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
+                          long ostride, long ooff, hipStream_t st, const int *perm) {
+    if constexpr (MT * KS2 < 8) {
+        return fail(PCX_ERR_UNSUPPORTED, "no k-fold MFMA instantiation for MT=%d KS2=%d", MT, KS2);
+    } else {
+        const size_t lds = bary_kfold_lds_bytes(h->kf, NT);
+        auto kern = k_bary_mfma_kfold<MT, KS2, NT>;
+        if (lds > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        const long per_wg = 64L * NT;
+        const long blocks = (N + per_wg - 1) / per_wg;
+        if (blocks > 0x7fffffffL) return fail(PCX_ERR_UNSUPPORTED, "batch too large for one launch");
+        hipLaunchKernelGGL(kern, dim3((unsigned)blocks, 1, (unsigned)m), dim3(256), lds, st, h->dims, h->kf, h->d_nodes, h->d_wts,
+                           h->grid_prod ? h->d_gsnodes : nullptr, frag_tab, d_pts, d_out, N, ostride, ooff, perm);
+        HIP_TRY(hipGetLastError());
+        return PCX_OK;
+    }
+}
+
+template <int MT, int NT>
+static int launch_kfold_mt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
+                           long ostride, long ooff, hipStream_t st, const int *perm) {
+    switch (h->kf.KS2) {
+#define CASE_KS(v) case v: return launch_kfold_t<MT, v, NT>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+        CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8) CASE_KS(9)
+        CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
+#undef CASE_KS
+    }
+    return fail(PCX_ERR_UNSUPPORTED, "no k-fold MFMA instantiation for KS2=%d", h->kf.KS2);
+}
+
+PCX_HIDDEN int bary_launch_kfold(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
+                                 long ostride, long ooff, hipStream_t st, const int *perm) {
+    // two column tiles per wave for throughput; one when the batch cannot fill the chip (same sums either way)
+    const bool two = N >= 65536 && h->nt == 2;
+#define GO(MTv) (two ? launch_kfold_mt<MTv, 2>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm) \
+                     : launch_kfold_mt<MTv, 1>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm))
+    switch (h->kf.MT) {
+        case 1: return GO(1);
+        case 2: return GO(2);
+        case 3: return GO(3);
+        case 4: return GO(4);
+    }
+#undef GO
+    return fail(PCX_ERR_UNSUPPORTED, "no k-fold MFMA instantiation for MT=%d", h->kf.MT);
+}

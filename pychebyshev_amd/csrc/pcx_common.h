@@ -56,6 +56,16 @@ struct BaryGridPlan {
     int MT;          // nchunks * TB row tiles
 };
 
+// k_bary_mfma_kfold (bary_kfold_kernels.h): 3-D tensors, rows = dimension 0 (MT tiles held in the accumulators),
+// K = dimensions 1 x 2 with the B operand formed per k-step
+#define PCX_KFOLD_PAD 16   // fragments behind the image the prefetch ring may read (zeroed, never multiplied)
+struct BaryKfoldPlan {
+    int n0, n1, n2;
+    int MT;          // ceil(n0 / 16), at most 4
+    int KS2;         // ceil(n2 / 4), at most 16
+    int trows;       // table rows per wave: max(16 MT, n1, 4 KS2)
+};
+
 // A "dim-0 group" of a multi-spec launch: specs that differ only in their derivative order along dimension 0
 // share ONE contraction of dimensions 1 .. d-1 (reference vectorized_eval_multi, barycentric.py:1098-1110:
 // contract the later dimensions, THEN apply D_0, then contract dimension 0).  The GEMM rows are laid out in

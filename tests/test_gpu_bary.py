@@ -1022,21 +1022,30 @@ def _grid_info(c):
     return [int(v) for v in info]
 
 
-@pytest.mark.parametrize("shape,dom", [
-    ((21, 21, 21), [[0, 1], [-1, 1], [2, 5]]),                  # RA = 2: 11 x 3 tiles, 6 k-steps
-    ((17, 19, 23), [[0, 1], [-1, 1], [2, 5]]),                  # unequal node counts, both tiled dimensions padded
-    ((30, 30, 30), [[-1, 1]] * 3),
-    ((40, 40, 40), [[-1, 1]] * 3),                              # no padding at all: 100 tiles of 10 k-steps
-    ((65, 65, 65), [[0, 2]] * 3),                               # 17 k-steps, 9 % more tiles, four-wave workgroups, A formed per chunk
-    ((7, 7, 7, 7, 7), [[0, 1]] * 5),                            # 13 k-steps and 27 % more tiles: stays on the row-code kernel
-    ((20, 16, 64), [[0, 2]] * 3),                               # 16 k-steps, nothing padded: grid
-    ((17, 12, 16, 52), [[0, 1]] * 4),                           # 13 k-steps, one outer dimension, nothing padded
-    ((18, 8, 20, 40), [[0, 1]] * 4),                            # one outer head dimension (18 > 16 nodes in front: no dim-0 groups)
-    ((17, 4, 16, 12, 33), [[0, 1]] * 5),                        # two outer head dimensions
-    ((20, 24), [[0, 1], [0, 2]]),                               # d = 2: head of one dimension -> not a grid plan (stays as it was)
+@pytest.mark.parametrize("shape,dom,kind", [
+    ((21, 21, 21), [[0, 1], [-1, 1], [2, 5]], 1),               # RA = 2: 11 x 3 tiles, 6 k-steps
+    ((17, 19, 23), [[0, 1], [-1, 1], [2, 5]], 1),               # unequal node counts, both tiled dimensions padded
+    ((40, 40, 40), [[-1, 1]] * 3, 1),                           # no padding at all: 100 tiles of 10 k-steps
+    ((65, 65, 65), [[0, 2]] * 3, 1),                            # 17 k-steps, 9 % more tiles, four-wave workgroups, A formed per chunk
+    ((7, 7, 7, 7, 7), [[0, 1]] * 5, 0),                         # 13 k-steps and 27 % more tiles: stays on the row-code kernel
+    ((20, 16, 64), [[0, 2]] * 3, 1),                            # 16 k-steps, nothing padded: grid
+    ((17, 12, 16, 52), [[0, 1]] * 4, 1),                        # 13 k-steps, one outer dimension, nothing padded
+    ((18, 8, 20, 40), [[0, 1]] * 4, 1),                         # one outer head dimension (18 > 16 nodes in front: no dim-0 groups)
+    ((17, 4, 16, 12, 33), [[0, 1]] * 5, 1),                     # two outer head dimensions
+    ((20, 24), [[0, 1], [0, 2]], 0),                            # d = 2: head of one dimension -> not a grid plan (stays as it was)
+    # k-fold plans (k_bary_mfma_kfold): dimension 0 in the accumulators, dimensions 1 x 2 folded into K
+    ((30, 30, 30), [[-1, 1]] * 3, 2),                           # 2 row tiles, 8 k-steps per i1, both padded (0.88 used)
+    ((32, 32, 32), [[0, 1], [-1, 1], [2, 5]], 2),               # nothing padded
+    ((31, 70, 30), [[0, 1]] * 3, 2),                            # 70 > 64 nodes in the middle: weights by division
+    ((48, 20, 47), [[0, 2]] * 3, 2),                            # 3 row tiles, 12 k-steps per i1 (ring of 12)
+    ((64, 9, 64), [[0, 1]] * 3, 2),                             # 4 row tiles, 16 k-steps per i1 (ring of 16)
+    ((15, 33, 31), [[-2, 1]] * 3, 2),                           # 1 row tile (dim-0 groups would pad 45 % here and stay off)
+    ((29, 29, 27), [[0, 1]] * 3, 2),                            # 7 k-steps per i1: ring of 14
+    ((30, 200, 30), [[0, 1]] * 3, 2),                           # long middle dimension: 232 table rows, one column tile per wave
 ])
-def test_grid_plans_against_oracle(oracle_mod, shape, dom):
-    """short MFMA plans on k_bary_mfma_grid (row tiles over the last two head dimensions, no row codes):
+def test_grid_plans_against_oracle(oracle_mod, shape, dom, kind):
+    """short MFMA plans on k_bary_mfma_grid (row tiles over the last two head dimensions, no row codes)
+    and on k_bary_mfma_kfold (3-D, whole row tiles along dimension 0, B formed per k-step):
     value and derivative specs vs the oracle at the 1e-12 bar for a small batch (split launch, one column tile per
     wave) and a large one (two column tiles, no split), multi-spec launches, exact-node and corner rows; a point's
     value does not depend on the batch it is evaluated in."""
@@ -1046,12 +1055,7 @@ def test_grid_plans_against_oracle(oracle_mod, shape, dom):
     c = ChebyshevApproximation.from_values(T, d, dom, list(shape))
     _set_kernel(c, 2)
     gi = _grid_info(c)
-    if d >= 3 and shape != (7, 7, 7, 7, 7):
-        assert gi[0] == 1, f"expected a grid plan for {shape}: {gi}"
-    if shape == (7, 7, 7, 7, 7):
-        assert gi[0] == 0
-    if d == 2:
-        assert gi[0] == 0
+    assert gi[0] == kind, f"expected plan kind {kind} for {shape}: {gi}"
     n_small, n_big = 777, 66_000
     pts = np.column_stack([rng.uniform(lo, hi, n_big) for lo, hi in dom])
     for k in range(d):
@@ -1088,24 +1092,27 @@ def test_grid_plans_against_oracle(oracle_mod, shape, dom):
     assert np.isnan(yb[3]) and np.isnan(yb[5]) and np.isfinite(np.delete(yb, [3, 5])).all()
 
 
-def test_grid_plan_equals_row_code_plan_to_rounding(oracle_mod, monkeypatch):
-    """The same model on the row-code form (PCX_BARY_GRID=0 at create) and on the grid form: both within the bar of the
-    oracle, and of each other at rounding level."""
+@pytest.mark.parametrize("shape,env,kinds", [
+    ((24, 24, 24), "PCX_BARY_GRID", (1, 0)),          # grid form vs row codes
+    ((30, 30, 30), "PCX_BARY_KFOLD", (2, 1)),         # k-fold form vs grid form
+])
+def test_grid_plan_equals_row_code_plan_to_rounding(oracle_mod, monkeypatch, shape, env, kinds):
+    """The same model on two MFMA forms (the newer one switched off through its environment knob at create): both within
+    the bar of the oracle, and of each other at rounding level."""
     rng = np.random.default_rng(77)
-    shape = (24, 24, 24)
     T = rng.standard_normal(shape)
     dom = [[-1, 1]] * 3
     pts = np.column_stack([rng.uniform(lo, hi, 70_000) for lo, hi in dom])
     res = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("PCX_BARY_GRID", flag)
+        monkeypatch.setenv(env, flag)
         c = ChebyshevApproximation.from_values(T, 3, dom, list(shape))
         _set_kernel(c, 2)
         res[flag] = (c.vectorized_eval_batch(pts, [0, 0, 0]), c.vectorized_eval_batch(pts, [0, 1, 0]), _grid_info(c)[0])
-    assert res["1"][2] == 1
+    assert (res["1"][2], res["0"][2]) == kinds
     om = _oracle_model(oracle_mod, c)
     for j, s in enumerate(([0, 0, 0], [0, 1, 0])):
         ref = oracle_mod.bary_eval_batch(om, pts[:2000], s)
         for flag in ("1", "0"):
-            assert_parity(res[flag][j][:2000], ref, 1e-12, f"grid={flag} {s}", spec_point_tol(s), floor=np.max(np.abs(T)))
+            assert_parity(res[flag][j][:2000], ref, 1e-12, f"{env}={flag} {s}", spec_point_tol(s), floor=np.max(np.abs(T)))
         assert np.max(np.abs(res["1"][j] - res["0"][j])) <= 1e-12 * np.max(np.abs(res["0"][j]))

@@ -294,22 +294,24 @@ def test_spline_with_equal_trailing_node_counts_runs_on_the_sq_kernel(monkeypatc
 
 
 @pytest.mark.gpu
-def test_spline_pieces_on_the_grid_mfma_kernel(oracle_mod):
-    """Round 4: pieces of 20 x 20 x 20 nodes run on k_bary_mfma_grid through the bucket permutation (`perm` argument):
-    two pieces, one of them with a third of the points, value and two derivative specs, a small and a large batch."""
+@pytest.mark.parametrize("nn,kind", [([20, 20, 20], 1), ([30, 12, 31], 2)])
+def test_spline_pieces_on_the_grid_mfma_kernel(oracle_mod, nn, kind):
+    """Round 4: pieces of 20 x 20 x 20 nodes run on k_bary_mfma_grid, pieces of 30 x 12 x 31 on k_bary_mfma_kfold, through the
+    bucket permutation (`perm` argument): two pieces, one of them with a third of the points, value and two derivative
+    specs, a small and a large batch."""
     import math
     f = lambda x, _=None: math.sin(1.3 * x[0]) * math.cos(0.7 * x[1]) + abs(x[0] - 0.2) * (1.0 + 0.1 * x[2]) + x[1] * x[2]
     dom = [[-1.0, 1.0], [0.0, 2.0], [-0.5, 0.5]]
-    sp = ChebyshevSpline(f, 3, dom, n_nodes=[20, 20, 20], knots=[[0.2], [], []])
+    sp = ChebyshevSpline(f, 3, dom, n_nodes=nn, knots=[[0.2], [], []])
     sp.build(verbose=False)
     assert len(sp._pieces) == 2
     for pc in sp._pieces:
         m = pc._model()
         gi = _lib.i32(np.zeros(4))
-        assert m.lib.pcx_bary_grid_info(m.handle, _lib.p_i32(gi)) == 0 and gi[0] == 1
+        assert m.lib.pcx_bary_grid_info(m.handle, _lib.p_i32(gi)) == 0 and gi[0] == kind
         info = _lib.i32(np.zeros(6))
         m.lib.pcx_bary_kernel_info(m.handle, _lib.p_i32(info))
-        assert info[0] == 2                                      # auto: the MFMA (grid) kernel for 20^3
+        assert info[0] == 2                                      # auto: the MFMA kernel (grid / k-fold form)
     rng = np.random.default_rng(44)
     pts = np.column_stack([rng.uniform(lo, hi, 150_000) for lo, hi in dom])
     models = [oracle_mod.BaryModel(p.nodes, p.weights, p.diff_matrices, p.tensor_values) for p in sp._pieces]

@@ -83,9 +83,9 @@ def main():
         mfma, _ = rate(shape, npts, variant=2)
         rows, _ = rate(shape, npts // 4 if size > 100_000 else npts, variant=1)
         kern = {4: "lane-per-point", 5: "lane-per-point sq", 1: "rows"}.get(
-            info[0], f"mfma{' grid' + str(info[7]) if info[6] else ''} MT={info[1]} KS={info[2]} split={info[5]}")
+            info[0], f"mfma{(' kfold' if info[6] == 2 else ' grid' + str(info[7])) if info[6] else ''} MT={info[1]} KS={info[2]} split={info[5]}")
         if info[0] != 2 and info[6]:
-            kern += f" (mfma: grid{info[7]})"
+            kern += " (mfma: kfold)" if info[6] == 2 else f" (mfma: grid{info[7]})"
         name = "x".join(str(n) for n in shape) if len(set(shape)) > 1 else f"{shape[0]}^{len(shape)}"
         print(f"{name:<16} {kern:<34} {auto[0]:11.4e} {auto[1]:6.3f} {auto[2]:6.3f}   {small[0]:13.4e} {small[1]:6.3f}   "
               f"{sq[0]:13.4e} {sq[1]:6.3f}   {mfma[0]:11.4e} {mfma[1]:6.3f}   {rows[0]:11.4e} {rows[1]:6.3f}")

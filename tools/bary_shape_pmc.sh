@@ -31,8 +31,8 @@ with open(out + "/pmc.txt", "w") as fh:
         fh.write(f"{k[:100]}\n   median {med/1e3:.1f} us, clock {gui/med if med else 0:.3f} GHz, kernel cycles {gui:.4e}\n")
         mf = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / 1024
         fh.write(f"   MFMA busy {mf:.4e} cycles per SIMD = {mf/gui if gui else 0:.3f} of the kernel; MFMA instr {m.get('SQ_INSTS_VALU_MFMA_MOPS_F64',0)/4:.4e} (16x16x4)\n")
-        va = m.get("SQ_INSTS_VALU", 0)
-        fh.write(f"   vector instr {va:.4e} ({va/1024:.4e} per SIMD; x4 cycles = {va*4/1024/gui if gui else 0:.3f} of the kernel), LDS instr {m.get('SQ_INSTS_LDS',0):.4e}, SALU {m.get('SQ_INSTS_SALU',0):.4e}, SMEM {m.get('SQ_INSTS_SMEM',0):.4e}, VMEM_RD {m.get('SQ_INSTS_VMEM_RD',0):.4e}\n")
+        va = m.get("SQ_INSTS_VALU", 0) - m.get("SQ_INSTS_VALU_MFMA_MOPS_F64", 0) / 4      # SQ_INSTS_VALU counts the matrix instructions too
+        fh.write(f"   other vector instr {va:.4e} ({va/1024:.4e} per SIMD; x4 cycles = {va*4/1024/gui if gui else 0:.3f} of the kernel), LDS instr {m.get('SQ_INSTS_LDS',0):.4e}, SALU {m.get('SQ_INSTS_SALU',0):.4e}, SMEM {m.get('SQ_INSTS_SMEM',0):.4e}, VMEM_RD {m.get('SQ_INSTS_VMEM_RD',0):.4e}\n")
         fh.write(f"   wait any / wave cycles {m.get('SQ_WAIT_INST_ANY',0)/max(1,m.get('SQ_WAVE_CYCLES',1)):.3f}, LDS wait / wave cycles {m.get('SQ_WAIT_INST_LDS',0)/max(1,m.get('SQ_WAVE_CYCLES',1)):.3f}, bank conflict cycles {m.get('SQ_LDS_BANK_CONFLICT',0):.3e}, waves {m.get('SQ_WAVES',0):.0f}\n")
 PY
 cat $OUT/pmc.txt

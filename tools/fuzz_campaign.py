@@ -327,6 +327,9 @@ def grid_case(rng, stats):
         if rng.random() < 0.3:
             nl = int(rng.integers(14, 41))
             shape = shape[:-3] + (nl, nl, nl)
+        if d == 3 and rng.random() < 0.4:                 # k_bary_mfma_kfold: whole row tiles along dimension 0
+            shape = (int(rng.choice([15, 16, 28, 29, 30, 31, 32, 45, 46, 47, 48, 61, 64])), int(rng.integers(2, 60)),
+                     int(rng.choice([27, 28, 29, 30, 31, 32, 35, 36, 43, 44, 47, 48, 63, 64])))
         if 2_000 <= np.prod(shape) <= 150_000:
             break
     dom = [[float(a), float(a + w)] for a, w in zip(rng.choice([0.0, -3.0, 100.0], d), rng.choice([0.01, 1.0, 25.0], d))]
@@ -337,7 +340,8 @@ def grid_case(rng, stats):
         return []
     gi = _lib.i32(np.zeros(4))
     m.lib.pcx_bary_grid_info(m.handle, _lib.p_i32(gi))
-    stats["grid_plans"] = stats.get("grid_plans", 0) + int(gi[0])
+    stats["grid_plans"] = stats.get("grid_plans", 0) + int(gi[0] == 1)
+    stats["kfold_plans"] = stats.get("kfold_plans", 0) + int(gi[0] == 2)
     n_big = int(rng.choice([66_000, 70_001]))
     pts = np.column_stack([rng.uniform(lo, hi, n_big) for lo, hi in dom])
     for _ in range(8):
@@ -445,7 +449,7 @@ def main():
           f"slider {stats.get('slider_worst', 0.0):.2e} over {stats.get('slider_launches', 0)} sliders, dim-0 groups "
           f"{stats.get('group_worst', 0.0):.2e} over {stats.get('group_launches', 0)} columns, {stats.get('group_shared', 0)} of them on a shared "
           f"contraction (bar 1e-12); grid-plan shapes {stats.get('grid_worst', 0.0):.2e} over {stats.get('grid_launches', 0)} launches "
-          f"({stats.get('grid_plans', 0)} models on k_bary_mfma_grid); device FD Greeks = host traversal bit for bit on "
+          f"({stats.get('grid_plans', 0)} models on k_bary_mfma_grid, {stats.get('kfold_plans', 0)} on k_bary_mfma_kfold); device FD Greeks = host traversal bit for bit on "
           f"{stats.get('ttfd_columns', 0)} columns; "
           f"failures: {len(failures)}")
     return 1 if failures else 0
