@@ -20,7 +20,8 @@
 // single query that waits for one wave's n1 KS2 MT matrix instructions (30^3: 480 = 13 us, 64^3: 4,096 = 0.11 ms).  A
 // version that finished dimension 1 in four chunks (b0 resident beside b1, chunk sums added in a fixed order, small batches
 // split over blockIdx.y) was built and measured: the larger table costs a workgroup per CU and 5-7 % of the throughput on
-// every shape (30^3 0.654 -> 0.616, 64^3 0.90 -> 0.85) -- not kept.
+// every shape (30^3 0.654 -> 0.616, 64^3 0.90 -> 0.85) -- not kept.  Four column tiles per wave (a lane per point, each fragment
+// feeding four matrix instructions; 204 VGPRs, two workgroups per CU) measured 2 % behind two on 26^3 ... 32^3 -- not kept either.
 #pragma once
 
 #include "pcx_common.h"
