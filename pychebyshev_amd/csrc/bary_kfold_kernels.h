@@ -16,6 +16,10 @@
 // matrix instructions share): two lanes share a point and take half the nodes each, and the weights stay unnormalised in the table -- the
 // factors 1 / sum go into the register operands.
 // Fragment image: frag[(i1 KS2 + s2) MT + t][lane] = T[16 t + (l & 15)][i1][4 s2 + (l >> 4)] (zero outside).
+// STR ("straddle", n2 = 4 KS2 - 2: 26, 30): K runs over PAIRS of i1 without padding -- 2 n2 elements in P = 2 KS2 - 1
+// k-steps instead of 2 KS2, the middle k-step holding the last two nodes of the first index (lane groups 0, 1) and the first
+// two of the second (lane groups 2, 3): its b1 factor is a per-lane select, and a lane's P b2 registers hold node
+// (4 s' + g) mod n2.  30^3: 900 matrix instructions per 32 points instead of 960.
 // No split launches: a small batch simply runs fewer waves, so a point's value never depends on its batch; the price is a
 // single query that waits for one wave's n1 KS2 MT matrix instructions (30^3: 480 = 13 us, 64^3: 4,096 = 0.11 ms).  A
 // version that finished dimension 1 in four chunks (b0 resident beside b1, chunk sums added in a fixed order, small batches
@@ -28,16 +32,21 @@
 
 __global__ void k_pack_fragments_kfold(const double *__restrict__ T, double *__restrict__ frag, BaryKfoldPlan kp) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = ((long)kp.n1 * kp.KS2 * kp.MT + PCX_KFOLD_PAD) * 64;
-    if (idx >= total) return;
+    const long nfrag = (long)kp.nbody * kp.P * kp.MT;
+    if (idx >= (nfrag + PCX_KFOLD_PAD) * 64) return;
     const int l = (int)(idx & 63);
     long f = idx >> 6;
-    if (f >= (long)kp.n1 * kp.KS2 * kp.MT) { frag[idx] = 0.0; return; }      // the pad the prefetch ring reads past the end
+    if (f >= nfrag) { frag[idx] = 0.0; return; }      // the pad the prefetch ring reads past the end
     const int t = (int)(f % kp.MT); f /= kp.MT;
-    const int s2 = (int)(f % kp.KS2);
-    const int i1 = (int)(f / kp.KS2);
-    const int i0 = 16 * t + (l & 15), i2 = 4 * s2 + (l >> 4);
-    frag[idx] = (i0 < kp.n0 && i2 < kp.n2) ? T[((long)i0 * kp.n1 + i1) * kp.n2 + i2] : 0.0;
+    const int sp = (int)(f % kp.P);                    // k-step within the loop body
+    const int body = (int)(f / kp.P);
+    const int i0 = 16 * t + (l & 15);
+    int i1 = body, i2 = 4 * sp + (l >> 4);
+    if (kp.str) {                                      // a body = two indices of dimension 1, its k-steps run over 2 n2 elements
+        i1 = 2 * body;
+        if (i2 >= kp.n2) { i2 -= kp.n2; ++i1; }
+    }
+    frag[idx] = (i0 < kp.n0 && i1 < kp.n1 && i2 < kp.n2) ? T[((long)i0 * kp.n1 + i1) * kp.n2 + i2] : 0.0;
 }
 
 // UNNORMALISED barycentric weights of one dimension into a point's LDS column, the work split between the two lanes that
@@ -113,8 +122,8 @@ __host__ __device__ constexpr int kfold_depth(int fr) {
 
 // 256 threads = 4 waves walking the fragment image in step (L1 sharing, as k_bary_mfma_grid), PW = 16 NT points per wave;
 // dynamic LDS = 4 * kp.trows * PW * 8 bytes.  grid = (point blocks, 1, specs).
-template <int MT, int KS2, int NT>
-__global__ void __launch_bounds__(256, 2)
+template <int MT, int KS2, int NT, bool STR>
+__global__ void __launch_bounds__(256, 2)      // STR holds 2 KS2 - 1 b2 registers per column tile: keep three waves per SIMD
 k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ nodes, const double *__restrict__ wts,
                   const double *__restrict__ snodes, const double *const *__restrict__ frag_tab,
                   const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
@@ -150,22 +159,27 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
     };
 
     // ---- b2 -> registers (the B layout: lane group g holds node 4 s2 + g of column c), normalised on the way ----
+    constexpr int P = STR ? 2 * KS2 - 1 : KS2;          // k-steps per loop body (STR: a body is two indices of dimension 1)
     const double r2 = weights_of(2, 0, 4 * KS2);
-    double B2[NT][KS2];
+    double B2[NT][P];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const double rp = __shfl(r2, 16 * nt + c, 64);
 #pragma unroll
-        for (int s = 0; s < KS2; ++s) B2[nt][s] = bw[(size_t)(4 * s + g) * PW + 16 * nt + c] * rp;
+        for (int s = 0; s < P; ++s) {
+            int row = 4 * s + g;
+            if (STR && row >= 4 * KS2 - 2) row -= 4 * KS2 - 2;
+            B2[nt][s] = bw[(size_t)row * PW + 16 * nt + c] * rp;
+        }
     }
     __syncthreads();
     // ---- b1 -> table (unnormalised; its factor goes into B2), main loop ----
-    const double r1 = weights_of(1, 0, kp.n1);
+    const double r1 = weights_of(1, 0, kp.n1 + 1);       // + a zero row: the second index of an odd n1's last pair
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const double rp = __shfl(r1, 16 * nt + c, 64);
 #pragma unroll
-        for (int s = 0; s < KS2; ++s) B2[nt][s] *= rp;
+        for (int s = 0; s < P; ++s) B2[nt][s] *= rp;
     }
     pcx_d4 acc[MT][NT];
 #pragma unroll
@@ -174,26 +188,38 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
     // a ring of DEPTH fragments runs ahead of the multiplication: the register a k-step has read is refilled at once with
     // the fragment DEPTH positions on (the image carries PCX_KFOLD_PAD fragments behind its end for the last refills)
-    constexpr int FR = KS2 * MT;
+    constexpr int FR = P * MT;
     constexpr int DEPTH = kfold_depth(FR);
     static_assert(DEPTH <= PCX_KFOLD_PAD, "ring deeper than the image's pad");
     double ring[DEPTH];
 #pragma unroll
     for (int i = 0; i < DEPTH; ++i) ring[i] = tf[(size_t)i * 64];
-    double w1c[NT];
+    constexpr int NW = STR ? 2 : 1;                      // b1 rows per body
+    double w1c[NW][NT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) w1c[nt] = bw[16 * nt + c];
-    for (int i1 = 0; i1 < kp.n1; ++i1) {
-        const int in = i1 + 1 < kp.n1 ? i1 + 1 : i1;
-        const gptr_t tn = tf + ((size_t)i1 * FR + DEPTH) * 64;
-        double w1n[NT];
+    for (int w = 0; w < NW; ++w)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w1n[nt] = bw[(size_t)in * PW + 16 * nt + c];
+        for (int nt = 0; nt < NT; ++nt) w1c[w][nt] = bw[(size_t)w * PW + 16 * nt + c];
+    for (int body = 0; body < kp.nbody; ++body) {
+        const int bn = body + 1 < kp.nbody ? body + 1 : body;
+        const gptr_t tn = tf + ((size_t)body * FR + DEPTH) * 64;
+        double w1n[NW][NT];
 #pragma unroll
-        for (int s = 0; s < KS2; ++s) {
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w1n[w][nt] = bw[(size_t)(NW * bn + w) * PW + 16 * nt + c];
+#pragma unroll
+        for (int s = 0; s < P; ++s) {
             double b[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b[nt] = B2[nt][s] * w1c[nt];
+            for (int nt = 0; nt < NT; ++nt) {
+                double w1 = w1c[0][nt];
+                if constexpr (STR) {
+                    if (s == KS2 - 1) w1 = g < 2 ? w1c[0][nt] : w1c[1][nt];
+                    else if (s >= KS2) w1 = w1c[1][nt];
+                }
+                b[nt] = B2[nt][s] * w1;
+            }
 #pragma unroll
             for (int t = 0; t < MT; ++t) {
                 const int q = s * MT + t;
@@ -206,7 +232,9 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
             }
         }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) w1c[nt] = w1n[nt];
+        for (int w = 0; w < NW; ++w)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) w1c[w][nt] = w1n[w][nt];
     }
     __syncthreads();
     // ---- b0 -> table, epilogue: rows (g + 4 j) of every tile, then the four lane groups, times 1 / sum of dimension 0 ----

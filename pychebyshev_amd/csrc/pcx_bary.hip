@@ -1586,7 +1586,7 @@ extern "C" int pcx_bary_kernel_info(pcx_bary *h, int32_t *info) {
     if (!h || !info) return fail(PCX_ERR_INVALID, "NULL argument");
     { const int keep = h->variant; h->variant = 0; info[0] = bary_effective_variant(h); h->variant = keep; }
     info[1] = h->mfma_ok ? (h->kfold_ok ? h->kf.MT : (h->grid_ok ? h->gp.MT : h->plan.MT)) : 0;
-    info[2] = h->mfma_ok ? (h->kfold_ok ? h->kf.n1 * h->kf.KS2 : h->plan.KS) : 0;
+    info[2] = h->mfma_ok ? (h->kfold_ok ? h->kf.nbody * h->kf.P : h->plan.KS) : 0;
     info[3] = h->mfma_ok ? (int32_t)(h->kfold_ok ? bary_kfold_lds_bytes(h->kf, h->nt)
                                                   : (h->grid_ok ? bary_grid_lds_bytes(h, h->nt) : mfma_lds_bytes(h->dims, h->nt)))
                          : (256 / h->lpp) * h->dims.sum_n * 8;

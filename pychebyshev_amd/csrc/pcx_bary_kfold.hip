@@ -13,6 +13,7 @@
 // PCX_BARY_KFOLD_EFF=<percent> replaces both bars (experiments).
 PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp) {
     const char *env = getenv("PCX_BARY_KFOLD"), *eff = getenv("PCX_BARY_KFOLD_EFF");    // read per handle
+    const char *strd = getenv("PCX_BARY_KFOLD_STRADDLE");                              // =0: pad n2 = 26, 30 instead (A/B)
     int bar = eff ? atoi(eff) : 0;
     if (bar <= 0 || bar > 100) bar = 0;
     if ((env && env[0] == '0') || dm.d != 3) return false;
@@ -21,14 +22,19 @@ PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp) {
     kp.MT = (kp.n0 + 15) / 16;
     kp.KS2 = (kp.n2 + 3) / 4;
     if (kp.MT * kp.KS2 < 8) return false;
-    kp.trows = std::max(std::max(16 * kp.MT, kp.n1), 4 * kp.KS2);
-    const long used = (long)kp.n0 * kp.n2, padded = 64L * kp.MT * kp.KS2;
+    kp.trows = std::max(std::max(16 * kp.MT, kp.n1 + 1), 4 * kp.KS2);
+    // n2 = 26, 30 (and 22): two indices of dimension 1 share a k-step instead of padding each to a multiple of four
+    kp.str = (kp.n2 % 4 == 2 && kp.KS2 >= 6 && kp.KS2 <= 8 && !(strd && strd[0] == '0')) ? 1 : 0;
+    if (kp.str && ((kp.n1 + 1) / 2) * (2 * kp.KS2 - 1) >= kp.n1 * kp.KS2) kp.str = 0;      // a short odd n1: nothing saved
+    kp.P = kp.str ? 2 * kp.KS2 - 1 : kp.KS2;
+    kp.nbody = kp.str ? (kp.n1 + 1) / 2 : kp.n1;
+    const long used = (long)kp.n0 * kp.n2, padded = 16L * kp.MT * (kp.str ? kp.n2 : 4 * kp.KS2);
     if (bar) return used * 100 >= padded * bar;
     return kp.MT <= 2 ? used * 100 > padded * 75 : used * 100 >= padded * 85;
 }
 
 PCX_HIDDEN size_t bary_kfold_frag_count(const BaryKfoldPlan &kp) {
-    return ((size_t)kp.n1 * kp.KS2 * kp.MT + PCX_KFOLD_PAD) * 64;
+    return ((size_t)kp.nbody * kp.P * kp.MT + PCX_KFOLD_PAD) * 64;
 }
 
 PCX_HIDDEN size_t bary_kfold_lds_bytes(const BaryKfoldPlan &kp, int nt) {       // per workgroup of four waves
@@ -42,14 +48,14 @@ PCX_HIDDEN int bary_pack_kfold(pcx_bary *h, const double *plain, double *frag) {
     return PCX_OK;
 }
 
-template <int MT, int KS2, int NT>
+template <int MT, int KS2, int NT, bool STR>
 static int launch_kfold_t(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
                           long ostride, long ooff, hipStream_t st, const int *perm) {
-    if constexpr (MT * KS2 < 8) {
+    if constexpr (MT * KS2 < 8 || (STR && (KS2 < 6 || KS2 > 8))) {
         return fail(PCX_ERR_UNSUPPORTED, "no k-fold MFMA instantiation for MT=%d KS2=%d", MT, KS2);
     } else {
         const size_t lds = bary_kfold_lds_bytes(h->kf, NT);
-        auto kern = k_bary_mfma_kfold<MT, KS2, NT>;
+        auto kern = k_bary_mfma_kfold<MT, KS2, NT, STR>;
         if (lds > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         const long per_wg = 64L * NT;
@@ -66,7 +72,8 @@ template <int MT, int NT>
 static int launch_kfold_mt(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
                            long ostride, long ooff, hipStream_t st, const int *perm) {
     switch (h->kf.KS2) {
-#define CASE_KS(v) case v: return launch_kfold_t<MT, v, NT>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
+#define CASE_KS(v) case v: return h->kf.str ? launch_kfold_t<MT, v, NT, true>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm) \
+                                        : launch_kfold_t<MT, v, NT, false>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, perm);
         CASE_KS(2) CASE_KS(3) CASE_KS(4) CASE_KS(5) CASE_KS(6) CASE_KS(7) CASE_KS(8) CASE_KS(9)
         CASE_KS(10) CASE_KS(11) CASE_KS(12) CASE_KS(13) CASE_KS(14) CASE_KS(15) CASE_KS(16)
 #undef CASE_KS

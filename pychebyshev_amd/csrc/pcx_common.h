@@ -63,7 +63,10 @@ struct BaryKfoldPlan {
     int n0, n1, n2;
     int MT;          // ceil(n0 / 16), at most 4
     int KS2;         // ceil(n2 / 4), at most 16
-    int trows;       // table rows per wave: max(16 MT, n1, 4 KS2)
+    int trows;       // table rows per wave: max(16 MT, n1 + 1, 4 KS2)
+    int str;         // 1: n2 = 4 KS2 - 2, K runs over pairs of i1 without padding (P = 2 KS2 - 1 k-steps per pair)
+    int P;           // k-steps per loop body: KS2, or 2 KS2 - 1
+    int nbody;       // loop bodies: n1, or ceil(n1 / 2)
 };
 
 // A "dim-0 group" of a multi-spec launch: specs that differ only in their derivative order along dimension 0

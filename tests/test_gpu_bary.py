@@ -1041,6 +1041,9 @@ def _grid_info(c):
     ((64, 9, 64), [[0, 1]] * 3, 2),                             # 4 row tiles, 16 k-steps per i1 (ring of 16)
     ((15, 33, 31), [[-2, 1]] * 3, 2),                           # 1 row tile (dim-0 groups would pad 45 % here and stay off)
     ((29, 29, 27), [[0, 1]] * 3, 2),                            # 7 k-steps per i1: ring of 14
+    ((30, 17, 26), [[0, 1]] * 3, 2),                            # n2 = 26 and an odd n1: pairs of i1 share a k-step, the last pair is half empty
+    ((32, 9, 22), [[-1, 3]] * 3, 2),                            # n2 = 22: 11 k-steps per pair
+    ((15, 33, 30), [[0, 1]] * 3, 2),                            # one row tile, straddled
     ((30, 200, 30), [[0, 1]] * 3, 2),                           # long middle dimension: 232 table rows, one column tile per wave
 ])
 def test_grid_plans_against_oracle(oracle_mod, shape, dom, kind):
@@ -1095,6 +1098,7 @@ def test_grid_plans_against_oracle(oracle_mod, shape, dom, kind):
 @pytest.mark.parametrize("shape,env,kinds", [
     ((24, 24, 24), "PCX_BARY_GRID", (1, 0)),          # grid form vs row codes
     ((30, 30, 30), "PCX_BARY_KFOLD", (2, 1)),         # k-fold form vs grid form
+    ((30, 31, 26), "PCX_BARY_KFOLD_STRADDLE", (2, 2)),  # k-fold form: pairs of i1 sharing a k-step vs n2 padded to 28
 ])
 def test_grid_plan_equals_row_code_plan_to_rounding(oracle_mod, monkeypatch, shape, env, kinds):
     """The same model on two MFMA forms (the newer one switched off through its environment knob at create): both within

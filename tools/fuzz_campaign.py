@@ -329,7 +329,7 @@ def grid_case(rng, stats):
             shape = shape[:-3] + (nl, nl, nl)
         if d == 3 and rng.random() < 0.4:                 # k_bary_mfma_kfold: whole row tiles along dimension 0
             shape = (int(rng.choice([15, 16, 28, 29, 30, 31, 32, 45, 46, 47, 48, 61, 64])), int(rng.integers(2, 60)),
-                     int(rng.choice([27, 28, 29, 30, 31, 32, 35, 36, 43, 44, 47, 48, 63, 64])))
+                     int(rng.choice([22, 26, 26, 27, 28, 29, 30, 30, 31, 32, 35, 36, 43, 44, 47, 48, 63, 64])))
         if 2_000 <= np.prod(shape) <= 150_000:
             break
     dom = [[float(a), float(a + w)] for a, w in zip(rng.choice([0.0, -3.0, 100.0], d), rng.choice([0.01, 1.0, 25.0], d))]
