@@ -42,6 +42,9 @@ Also on the JSON line:
                batch (10-D, rank 16, 12.5 M points = 10^8 / 8; `full_batch_one_gpu`: all 10^8 x 10 in ONE launch on one
                GPU) and config 1 (12 x 12, 10^4 points: microseconds
                per call, GPU and CPU) -- same timing discipline, never mixed into `value`.
+  midsize      N = 1 only: device-resident value evaluations of mid-size full tensors (21^3 ... 65^3, 64^4: the shapes
+               VERDICT r3 #6 names and their neighbours) on the kernel auto picks, HIP events around ten launches each:
+               kernel, point-evals/s and the fraction of the FP64 matrix peak per shape.
   cpu_baseline the CPU oracle (C restatement of the reference, OpenMP) on all usable
                host cores, on the per-GPU CPU share (16) and the reference's NumPy shape on
                one core -- bounded samples of the same workload, rank 0, N = 1 only.
@@ -904,6 +907,59 @@ def run_rank(args) -> int:
     head = measure(wl, args.steps, args.warmup, headline_mode)
     gathers = gather_report(wl, args.steps, args.warmup, head) if multi else None
 
+    def midsize_companion():
+        """Mid-size full tensors (VERDICT r3 #6 names 21^3, 30^3, 40^3, 65^3, 64^4): device-resident vectorized_eval_batch of
+        random-value tensors on the kernel auto picks, timed with HIP events on the handle's stream; frac = the reference's
+        nested-reduction flop count (barycentric.py:1035-1046) over the FP64 matrix peak.  Parity of these kernel forms:
+        tests/test_gpu_bary.py::test_grid_plans_against_oracle."""
+        from pychebyshev_amd import ChebyshevApproximation
+        rows = []
+        for shape in ((21,) * 3, (30,) * 3, (32,) * 3, (40,) * 3, (48,) * 3, (64,) * 3, (65,) * 3, (64,) * 4):
+            d = len(shape)
+            rng = np.random.default_rng(d * 1000 + shape[0])
+            c = ChebyshevApproximation.from_values(rng.standard_normal(shape), d, [[-1.0, 1.0]] * d, list(shape))
+            c.to_device()
+            m = c._model()
+            kinfo, ginfo = (ctypes.c_int32 * 6)(), (ctypes.c_int32 * 4)()
+            chk(lib.pcx_bary_kernel_info(m.handle, kinfo))
+            chk(lib.pcx_bary_grid_info(m.handle, ginfo))
+            npts = 1_000_000 if int(np.prod(shape)) < 4_000_000 else 125_000
+            pts = rng.uniform(-1, 1, (npts, d))
+            d_pts, d_out = ctypes.c_void_p(), ctypes.c_void_p()
+            chk(lib.pcx_dev_malloc(dev, pts.nbytes, ctypes.byref(d_pts)))
+            chk(lib.pcx_dev_malloc(dev, npts * 8, ctypes.byref(d_out)))
+            try:
+                chk(lib.pcx_memcpy_h2d(dev, d_pts, pts.ctypes.data_as(ctypes.c_void_p), pts.nbytes))
+                st = ctypes.c_void_p()
+                chk(lib.pcx_bary_stream(m.handle, ctypes.byref(st)))
+                spec = _lib.i32([0] * d)
+                reps = 10
+                for _ in range(3):
+                    chk(lib.pcx_bary_eval_batch_dev(m.handle, d_pts, npts, _lib.p_i32(spec), d_out, st))
+                e0, e1 = new_event(), new_event()
+                chk(lib.pcx_event_record(e0, st))
+                for _ in range(reps):
+                    chk(lib.pcx_bary_eval_batch_dev(m.handle, d_pts, npts, _lib.p_i32(spec), d_out, st))
+                chk(lib.pcx_event_record(e1, st))
+                dev_sync()
+                ms = elapsed_ms(e0, e1) / reps
+            finally:
+                lib.pcx_dev_free(dev, d_pts)
+                lib.pcx_dev_free(dev, d_out)
+                free_events()
+            fma, size = 0, int(np.prod(shape))
+            for n_ in reversed(shape):
+                fma += size
+                size //= n_
+            kern = {4: "k_bary_small", 5: "k_bary_sq", 1: "k_bary_rows"}.get(
+                int(kinfo[0]), {1: "k_bary_mfma_grid", 2: "k_bary_mfma_kfold"}.get(int(ginfo[0]), "k_bary_mfma"))
+            rows.append({"shape": "x".join(str(v) for v in shape), "kernel": kern, "points": npts, "ms_per_launch": ms,
+                         "value": npts / (ms * 1e-3), "unit": "point-evals/s",
+                         "frac": 2.0 * fma * npts / (ms * 1e-3) / (FP64_MFMA_PEAK_TFLOPS * 1e12)})
+            del c, m
+        return {"what": "device-resident value evaluations of mid-size full tensors, auto kernel choice (DESIGN 3.1d-f)",
+                "peak": FP64_MFMA_PEAK_TFLOPS, "peak_unit": "TFLOP/s", "shapes": rows}
+
     def companion(name):
         cwl = make_workload(_lib, name, 0)
         # a TT step is 0.9 ms (3 ms for the 10-D model): 20 of them end inside the clock transient that follows the
@@ -1052,6 +1108,11 @@ def run_rank(args) -> int:
                     out["baseline_error"] = f"{type(exc).__name__}: {exc}"
             companions[field] = out
         if world == 1:
+            try:
+                companions["midsize"] = midsize_companion()
+            except Exception as exc:                     # noqa: BLE001
+                sys.stderr.write(f"bench.py: mid-size shapes companion failed: {type(exc).__name__}: {exc}\n")
+                companions["midsize"] = {"error": f"{type(exc).__name__}: {exc}"}
             try:
                 companions["c1"] = config1_companion()
             except Exception as exc:                     # noqa: BLE001

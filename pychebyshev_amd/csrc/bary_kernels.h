@@ -117,7 +117,8 @@ __device__ __forceinline__ void bary_g0_finish(const BaryG0 &gs, const double *_
 // (reference barycentric.py:1039-1045 / :1083-1094): first node with |x - node| < 1e-14
 // gives a one-hot row, otherwise u_j = w_j / (x - node_j), b_j = u_j / sum(u).
 // Written to dst[j * stride].  (The division-free form of bary_weights.h was tried here in round 4: 11^5 +1 %, 7^5 -4 %,
-// 15^4 -2 %, the 4-D shapes unchanged -- the row-code kernel's prologue is latency, not instruction count; not kept.)
+// 15^4 -2 %, the 4-D shapes unchanged, 64^2 -11 %, 40 x 64 -13 % -- the row-code kernel's prologue is latency (three dependent
+// passes per dimension against divisions that pipeline), not instruction count; not kept.)
 // ---------------------------------------------------------------------------------
 __device__ __forceinline__ void bary_weights_1d(double x, const double *__restrict__ nodes,
                                                 const double *__restrict__ wts, int n, double *dst,

@@ -214,7 +214,10 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
         if (d <= 4 && nl <= 64 && outer_rows * 64 * (long)sizeof(double) <= 64 * 1024 && total <= (1L << 22)) {
             for (int v : kNlp)
                 if (v >= nl) { h->small_nlp = v; break; }
-            h->small_preferred = total <= kSmallTensorElems && nl <= 48;
+            // ... and 2-D tensors with a last dimension of 49 ... 64 nodes while the first has at most 48 (round 4,
+            // lane-per-point / MFMA in 1e9 pts/s: 20 x 64 5.8 / 2.2, 30 x 50 3.5 / 2.6, 40 x 64 2.7 / 1.9, 48 x 64 2.1 / 1.9; 50^2
+            // 2.0 / 2.1, 60^2 1.6 / 1.9, 64^2 1.6 / 1.7; 3-D shapes of that kind -- 8 x 8 x 50 -- stay on the MFMA kernel)
+            h->small_preferred = total <= kSmallTensorElems && (nl <= 48 || (d == 2 && n_nodes[0] <= 48));
             // mid-size tensors with equal trailing node counts: both trailing weight vectors in registers (k_bary_sq)
             if (d >= 2 && n_nodes[d - 2] == nl && ((nl >= 4 && nl <= 24) || nl == 26 || nl == 28 || nl == 30 || nl == 32) &&
                 (outer_rows - nl) * 64 * (long)sizeof(double) <= 48 * 1024) {

@@ -177,6 +177,8 @@ def test_derivative_tensor_kernel_is_bit_identical_to_oracle(bs5d, oracle_mod):
     ((100, 90, 70), [[0, 1], [-2, -1], [5, 9]]),           # sum_n = 260: head part 190 rows + tail part 70 rows
     ((200, 80), [[0.0, 1.0], [0.0, 1.0]]),                 # sum_n = 280: 144 KB weight table, one column tile per wave
     ((250, 250), [[0.0, 1.0], [0.0, 1.0]]),                # sum_n = 500: the table no longer fits LDS -> rows kernel
+    ((20, 64), [[0.0, 1.0], [-3.0, 1.0]]),                 # 2-D, last dimension 49 ... 64 nodes, first <= 48: lane per point (round 4)
+    ((60, 60), [[0.0, 1.0], [-3.0, 1.0]]),                 # ... first dimension beyond 48: the MFMA kernel
 ])
 def test_random_shapes_against_oracle(oracle_mod, shape, dom):
     rng = np.random.default_rng(sum(shape))
@@ -208,8 +210,10 @@ def test_random_shapes_against_oracle(oracle_mod, shape, dom):
         assert info[0] == 1 and not mfma_planned, "expected the rows kernel for this shape"
     elif d >= 8 or shape in ((2, 200), (16,) * 4, (100, 90, 70), (200, 80)):
         assert info[0] == 2, "expected the MFMA kernel for this shape"
-    elif shape == (14, 13, 15):
-        assert info[0] == 4 and mfma_planned      # 2730 elements: lane-per-point by default, MFMA plan (K = 195) also run
+    elif shape in ((14, 13, 15), (20, 64)):
+        assert info[0] == 4 and mfma_planned      # 2730 / 1280 elements: lane-per-point by default, the MFMA plan also run
+    elif shape == (60, 60):
+        assert info[0] == 2
 
 
 def test_both_mfma_forms_are_bit_identical(bs5d):
