@@ -188,7 +188,11 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
     // MFMA plan + row/k codes
     h->mfma_ok = plan_mfma(h->dims, h->plan);
     if (h->mfma_ok) {
-        h->nt = (h->plan.KS > 32) ? 1 : 2;
+        // two column tiles per wave while the B operands fit the register file beside them: up to 32 k-steps, 36 and 40 with
+        // narrow codes (232 ... 256 VGPRs at two waves per SIMD; round 4, one against two column tiles: 12^4 0.642 -> 0.683,
+        // 12 x 12 x 10 x 16 0.629 -> 0.682, 6 x 6 x 6 x 12 x 12 0.644 -> 0.692 -- each fragment load feeds two matrix instructions)
+        const bool narrow = h->plan.split <= PCX_CODE_FIELDS && d - h->plan.split <= PCX_CODE_FIELDS;
+        h->nt = (h->plan.KS <= 32 || (narrow && h->plan.KS <= 40)) ? 2 : 1;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->nt = 1;
         if (mfma_lds_bytes(h->dims, h->nt) > 150 * 1024) h->mfma_ok = false;
     }
@@ -679,6 +683,13 @@ static int launch_mfma_nf(pcx_bary *h, const double *const *frag_tab, int m, con
         switch (h->plan.KS) {
 #define CASE_KS(v) case v: return launch_mfma_t<v, 1, WIDE, NF>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
             CASE_KS(36) CASE_KS(40) CASE_KS(44) CASE_KS(48) CASE_KS(52) CASE_KS(56) CASE_KS(60) CASE_KS(64)
+#undef CASE_KS
+        }
+    }
+    if constexpr (NT == 2 && !WIDE) {
+        switch (h->plan.KS) {
+#define CASE_KS(v) case v: return launch_mfma_t<v, 2, WIDE, NF>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
+            CASE_KS(36) CASE_KS(40)
 #undef CASE_KS
         }
     }

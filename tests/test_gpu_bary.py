@@ -1037,6 +1037,8 @@ def _grid_info(c):
     ((18, 8, 20, 40), [[0, 1]] * 4, 1),                         # one outer head dimension (18 > 16 nodes in front: no dim-0 groups)
     ((17, 4, 16, 12, 33), [[0, 1]] * 5, 1),                     # two outer head dimensions
     ((20, 24), [[0, 1], [0, 2]], 0),                            # d = 2: head of one dimension -> not a grid plan (stays as it was)
+    ((12, 12, 12, 12), [[0, 1]] * 4, 0),                        # row codes, 36 k-steps: two column tiles per wave from round 4 (232 VGPRs)
+    ((12, 12, 10, 16), [[-1, 1]] * 4, 0),                       # ... 40 k-steps (254 VGPRs)
     # k-fold plans (k_bary_mfma_kfold): dimension 0 in the accumulators, dimensions 1 x 2 folded into K
     ((30, 30, 30), [[-1, 1]] * 3, 2),                           # 2 row tiles, 8 k-steps per i1, both padded (0.88 used)
     ((32, 32, 32), [[0, 1], [-1, 1], [2, 5]], 2),               # nothing padded
