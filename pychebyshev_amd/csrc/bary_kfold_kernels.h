@@ -1,6 +1,8 @@
 // bary_kfold_kernels.h -- k_bary_mfma_kfold: the MFMA form of the barycentric contraction for 3-D tensors whose FIRST
 // dimension fills whole row tiles (n0 = 28 ... 32, 45 ... 48, 61 ... 64, 15, 16) -- round 4.
 //
+// ("Dimension 0 / 1 / 2" below are ROLES: the planner gives the rows to whichever tensor dimension fills its row tiles best
+// -- 20 x 16 x 64 runs with its last dimension as rows --, BaryKfoldPlan::dim / stride; cubes keep the natural order.)
 // Same contraction as k_bary_mfma / k_bary_mfma_grid (reference barycentric.py:1035-1046), folded the other way round:
 //     y(p) = sum_{i0} b0[i0,p] ( sum_{(i1,i2)} T[i0][i1][i2] b1[i1,p] b2[i2,p] )
 // rows M = n0 (1 ... 4 row tiles that stay in the accumulators for the WHOLE contraction), K = n1 n2 (hundreds to
@@ -46,7 +48,7 @@ __global__ void k_pack_fragments_kfold(const double *__restrict__ T, double *__r
         i1 = 2 * body;
         if (i2 >= kp.n2) { i2 -= kp.n2; ++i1; }
     }
-    frag[idx] = (i0 < kp.n0 && i1 < kp.n1 && i2 < kp.n2) ? T[((long)i0 * kp.n1 + i1) * kp.n2 + i2] : 0.0;
+    frag[idx] = (i0 < kp.n0 && i1 < kp.n1 && i2 < kp.n2) ? T[i0 * kp.stride[0] + i1 * kp.stride[1] + i2 * kp.stride[2]] : 0.0;
 }
 
 // UNNORMALISED barycentric weights of one dimension into a point's LDS column, the work split between the two lanes that
@@ -143,10 +145,11 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
     const long pidx0 = base + fpoint;
     const bool valid = pidx0 < N;
     const long prow = valid ? (perm ? (long)perm[pidx0] : pidx0) : 0;
-    // weights of dimension k into table rows [row, row + n_k), zeros up to row `upto` (rows a padded index reads)
-    auto weights_of = [&](int k, int row, int upto) -> double {
+    // weights of the dimension in `role` into table rows [row, row + n), zeros up to row `upto` (rows a padded index reads)
+    auto weights_of = [&](int role, int row, int upto) -> double {
         double r = 1.0;
         if (former) {
+            const int k = kp.dim[role];                     // the tensor dimension that plays this role
             const double *nd = nodes + dims.off[k];
             const double x = valid ? pts[prow * 3 + k] : nd[0];
             double *col = bw + (size_t)row * PW + fpoint;

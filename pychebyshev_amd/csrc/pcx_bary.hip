@@ -349,15 +349,23 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
 
     // short plans: the grid form (bary_grid_kernels.h) -- unless the shape can share GEMMs between specs one order apart
     // (dim-0 groups above), which needs the slab packing of the row-code form
-    if (h->mfma_ok && !h->g0_ok && !(h->plan.split > PCX_CODE_FIELDS || d - h->plan.split > PCX_CODE_FIELDS)) {
-        // 3-D tensors whose first dimension fills whole row tiles: the k-fold form (bary_kfold_kernels.h) ahead of the grid form
+    if (h->mfma_ok && !(h->plan.split > PCX_CODE_FIELDS || d - h->plan.split > PCX_CODE_FIELDS)) {
+        // 3-D tensors one of whose dimensions fills whole row tiles: the k-fold form (bary_kfold_kernels.h) ahead of the grid
+        // form -- and of the dim-0 groups: 9 x 48 x 30 runs at 0.30 of the peak on the row-code form a group would share, the
+        // k-fold form (rows = the 48) takes every launch of it to 0.8
         h->kfold_ok = bary_plan_kfold(h->dims, h->kf);
         if (h->kfold_ok) {
+            const int nt_rc = h->nt;
             h->nt = 2;
             if (bary_kfold_lds_bytes(h->kf, 2) > (size_t)72 * 1024) h->nt = 1;      // two workgroups per CU
-            if (bary_kfold_lds_bytes(h->kf, h->nt) > (size_t)150 * 1024) h->kfold_ok = false;   // a very long middle dimension
+            if (bary_kfold_lds_bytes(h->kf, h->nt) > (size_t)150 * 1024) { h->kfold_ok = false; h->nt = nt_rc; }   // a very long middle dimension
         }
-        if (!h->kfold_ok) h->grid_ok = bary_plan_grid(h->dims, h->plan, h->gp);
+        if (h->kfold_ok && h->g0_ok) {
+            h->g0_ok = false;
+            (void)hipFree(h->d_rowcode_g0);
+            h->d_rowcode_g0 = nullptr;
+        }
+        if (!h->kfold_ok && !h->g0_ok) h->grid_ok = bary_plan_grid(h->dims, h->plan, h->gp);
         if (h->grid_ok) {
             h->nt = h->plan.KS > 32 ? 1 : 2;                       // the table is per wave and holds one part at a time
             const size_t cap = (size_t)(h->gp.wpb == 4 ? 150 : 64) * 1024;

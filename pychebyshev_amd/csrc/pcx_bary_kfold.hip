@@ -4,33 +4,57 @@
 #include "pcx_bary_internal.h"
 #include "bary_kfold_kernels.h"
 
-// Eligible: three dimensions, n0 <= 64 (four row tiles in the accumulators), n2 <= 64 (sixteen B operands of dimension 2 in
+// Eligible: three dimensions -- any of them may play the rows, see kfold_try --, n0 <= 64 (four row tiles in the accumulators), n2 <= 64 (sixteen B operands of dimension 2 in
 // registers), at least 8 fragments per i1 (the prefetch ring), and little padding: the share n0 / (16 MT) x n2 / (4 KS2) of
 // real products must be at least 0.85 (30^3: 0.88, 32^3 / 48^3 / 64^3: 1.0) -- above 0.75 for one or two row tiles, where
 // the grid form's short tiles cost more than the padding: measured with PCX_BARY_KFOLD_EFF=50 against the shipped rule
 // (profiles/r04_bary_rate_probe_kfold50.txt) 26^3 0.556 / 0.472 (grid), 29^3 0.615 / 0.498, 24^3 0.552 / 0.556, 23^3 0.497 / 0.493,
 // 20^3 0.444 / 0.484, 36^3 0.614 / 0.649, 40^3 0.676 / 0.691, 52^3 0.724 / 0.767.  PCX_BARY_KFOLD=0 switches the form off,
 // PCX_BARY_KFOLD_EFF=<percent> replaces both bars (experiments).
+// One assignment of the three tensor dimensions to the roles (rows, loop, b2 registers): fills kp, returns the share of real
+// products in percent (0: not eligible).
+static long kfold_try(const BaryDims &dm, int dr, int da, int db, bool straddle, BaryKfoldPlan &kp) {
+    kp.dim[0] = dr; kp.dim[1] = da; kp.dim[2] = db;
+    const long st[3] = {(long)dm.n[1] * dm.n[2], (long)dm.n[2], 1L};
+    for (int q = 0; q < 3; ++q) kp.stride[q] = st[kp.dim[q]];
+    kp.n0 = dm.n[dr]; kp.n1 = dm.n[da]; kp.n2 = dm.n[db];
+    if (kp.n0 > 64 || kp.n2 > 64 || kp.n2 < 2) return 0;
+    kp.MT = (kp.n0 + 15) / 16;
+    kp.KS2 = (kp.n2 + 3) / 4;
+    if (kp.MT * kp.KS2 < 8) return 0;
+    kp.trows = std::max(std::max(16 * kp.MT, kp.n1 + 1), 4 * kp.KS2);
+    // n2 = 26, 30 (and 22): two indices of dimension 1 share a k-step instead of padding each to a multiple of four
+    kp.str = (kp.n2 % 4 == 2 && kp.KS2 >= 6 && kp.KS2 <= 8 && straddle) ? 1 : 0;
+    if (kp.str && ((kp.n1 + 1) / 2) * (2 * kp.KS2 - 1) >= kp.n1 * kp.KS2) kp.str = 0;      // a short odd n1: nothing saved
+    kp.P = kp.str ? 2 * kp.KS2 - 1 : kp.KS2;
+    kp.nbody = kp.str ? (kp.n1 + 1) / 2 : kp.n1;
+    const long used = (long)kp.n0 * kp.n1 * kp.n2, padded = 16L * kp.MT * kp.nbody * kp.P * 4;
+    return used * 10000 / padded;                     // hundredths of a percent
+}
+
+// What the matrix pipe makes of a row-tile count (one multiply and one fragment load feed MT x NT matrix instructions):
+// measured busy x clock of the unpadded shapes, 15 x 33 x 31 0.65, 32^3 0.75, 48^3 0.84, 64^3 0.91 -- relative weights for
+// choosing between assignments of equal padding (20 x 16 x 64: 64 rows in four tiles, not 16 rows in one).
+static long kfold_tile_weight(int MT) { return MT >= 4 ? 100 : (MT == 3 ? 93 : (MT == 2 ? 83 : 72)); }
+
 PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp) {
     const char *env = getenv("PCX_BARY_KFOLD"), *eff = getenv("PCX_BARY_KFOLD_EFF");    // read per handle
     const char *strd = getenv("PCX_BARY_KFOLD_STRADDLE");                              // =0: pad n2 = 26, 30 instead (A/B)
     int bar = eff ? atoi(eff) : 0;
     if (bar <= 0 || bar > 100) bar = 0;
     if ((env && env[0] == '0') || dm.d != 3) return false;
-    kp.n0 = dm.n[0]; kp.n1 = dm.n[1]; kp.n2 = dm.n[2];
-    if (kp.n0 > 64 || kp.n2 > 64 || kp.n2 < 2) return false;
-    kp.MT = (kp.n0 + 15) / 16;
-    kp.KS2 = (kp.n2 + 3) / 4;
-    if (kp.MT * kp.KS2 < 8) return false;
-    kp.trows = std::max(std::max(16 * kp.MT, kp.n1 + 1), 4 * kp.KS2);
-    // n2 = 26, 30 (and 22): two indices of dimension 1 share a k-step instead of padding each to a multiple of four
-    kp.str = (kp.n2 % 4 == 2 && kp.KS2 >= 6 && kp.KS2 <= 8 && !(strd && strd[0] == '0')) ? 1 : 0;
-    if (kp.str && ((kp.n1 + 1) / 2) * (2 * kp.KS2 - 1) >= kp.n1 * kp.KS2) kp.str = 0;      // a short odd n1: nothing saved
-    kp.P = kp.str ? 2 * kp.KS2 - 1 : kp.KS2;
-    kp.nbody = kp.str ? (kp.n1 + 1) / 2 : kp.n1;
-    const long used = (long)kp.n0 * kp.n2, padded = 16L * kp.MT * (kp.str ? kp.n2 : 4 * kp.KS2);
-    if (bar) return used * 100 >= padded * bar;
-    return kp.MT <= 2 ? used * 100 > padded * 75 : used * 100 >= padded * 85;
+    // the roles go to the assignment with the least padding; the natural order (rows = dimension 0, b2 = the contiguous last
+    // dimension) wins ties, so cubes are packed and summed as before
+    static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    long best = 0, best_w = 0;
+    BaryKfoldPlan cand;
+    for (const auto &pm : perms) {
+        const long sc = kfold_try(dm, pm[0], pm[1], pm[2], !(strd && strd[0] == '0'), cand);
+        if (sc * kfold_tile_weight(cand.MT) > best_w) { best_w = sc * kfold_tile_weight(cand.MT); best = sc; kp = cand; }
+    }
+    if (!best) return false;
+    if (bar) return best >= bar * 100L;
+    return kp.MT <= 2 ? best > 7500 : best >= 8500;
 }
 
 PCX_HIDDEN size_t bary_kfold_frag_count(const BaryKfoldPlan &kp) {

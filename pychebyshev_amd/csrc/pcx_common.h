@@ -60,7 +60,9 @@ struct BaryGridPlan {
 // K = dimensions 1 x 2 with the B operand formed per k-step
 #define PCX_KFOLD_PAD 16   // fragments behind the image the prefetch ring may read (zeroed, never multiplied)
 struct BaryKfoldPlan {
-    int n0, n1, n2;
+    int dim[3];      // the tensor dimension in each role: dim[0] -> rows, dim[1] -> the loop ("i1"), dim[2] -> the b2 registers
+    long stride[3];  // element strides of those dimensions in the C-order tensor
+    int n0, n1, n2;  // their node counts (the names below are ROLES: "dimension 0" = dim[0], ...)
     int MT;          // ceil(n0 / 16), at most 4
     int KS2;         // ceil(n2 / 4), at most 16
     int trows;       // table rows per wave: max(16 MT, n1 + 1, 4 KS2)

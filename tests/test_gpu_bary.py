@@ -1032,7 +1032,9 @@ def _grid_info(c):
     ((40, 40, 40), [[-1, 1]] * 3, 1),                           # no padding at all: 100 tiles of 10 k-steps
     ((65, 65, 65), [[0, 2]] * 3, 1),                            # 17 k-steps, 9 % more tiles, four-wave workgroups, A formed per chunk
     ((7, 7, 7, 7, 7), [[0, 1]] * 5, 0),                         # 13 k-steps and 27 % more tiles: stays on the row-code kernel
-    ((20, 16, 64), [[0, 2]] * 3, 1),                            # 16 k-steps, nothing padded: grid
+    ((20, 16, 64), [[0, 2]] * 3, 2),                            # k-fold with the LAST dimension as rows (64 = four whole tiles)
+    ((40, 30, 12), [[0, 1], [-1, 1], [2, 5]], 2),               # k-fold, rows = dimension 1 (30), b2 registers = dimension 0 (40)
+    ((9, 48, 30), [[0, 1], [-1, 1], [2, 5]], 2),                # k-fold, rows = dimension 1 (48), straddled over dimension 2 (30)
     ((17, 12, 16, 52), [[0, 1]] * 4, 1),                        # 13 k-steps, one outer dimension, nothing padded
     ((18, 8, 20, 40), [[0, 1]] * 4, 1),                         # one outer head dimension (18 > 16 nodes in front: no dim-0 groups)
     ((17, 4, 16, 12, 33), [[0, 1]] * 5, 1),                     # two outer head dimensions
