@@ -1,5 +1,5 @@
-// bary_kfold_kernels.h -- k_bary_mfma_kfold: the MFMA form of the barycentric contraction for 3-D tensors whose FIRST
-// dimension fills whole row tiles (n0 = 28 ... 32, 45 ... 48, 61 ... 64, 15, 16) -- round 4.
+// bary_kfold_kernels.h -- k_bary_mfma_kfold: the MFMA form of the barycentric contraction for 3-D tensors ONE of whose
+// dimensions fills whole row tiles (26 ... 32, 44 ... 48, 59 ... 64 nodes; 13 ... 16 beside a long last dimension) -- round 4.
 //
 // ("Dimension 0 / 1 / 2" below are ROLES: the planner gives the rows to whichever tensor dimension fills its row tiles best
 // -- 20 x 16 x 64 runs with its last dimension as rows --, BaryKfoldPlan::dim / stride; cubes keep the natural order.)
@@ -13,10 +13,10 @@
 // FMAs, four table reads and 17 wait states per 16 matrix instructions; here a k-step carries half a multiply per
 // matrix instruction.  Padding: n0 to 16 MT rows, n2 to 4 KS2 columns per i1 (30^3: 0.94 x 0.94, as the grid plan).
 // The per-wave LDS table holds ONE dimension's weights at a time (b2 -> registers, then b1 for the loop, then b0 for the
-// epilogue): max(16 MT, n1, 4 KS2) rows of PW doubles.  Forming the weights is the kernel's only vector work of any size (30^3,
-// first version: 1,550 of a wave's 2,200 non-matrix vector instructions, all of them 12 % of the cycles of the pipe the
-// matrix instructions share): two lanes share a point and take half the nodes each, and the weights stay unnormalised in the table -- the
-// factors 1 / sum go into the register operands.
+// epilogue): max(16 MT, n1 + 1, 4 KS2) rows of PW doubles.  Forming the weights is the kernel's only vector work of any size
+// (30^3, first version: 1,550 of a wave's 2,200 non-matrix vector instructions, all of them 12 % of the cycles of the pipe the
+// matrix instructions share): two lanes share a point and take half the nodes each, and the weights stay unnormalised in the
+// table -- the factors 1 / sum go into the register operands.
 // Fragment image: frag[(i1 KS2 + s2) MT + t][lane] = T[16 t + (l & 15)][i1][4 s2 + (l >> 4)] (zero outside).
 // STR ("straddle", n2 = 4 KS2 - 2: 26, 30): K runs over PAIRS of i1 without padding -- 2 n2 elements in P = 2 KS2 - 1
 // k-steps instead of 2 KS2, the middle k-step holding the last two nodes of the first index (lane groups 0, 1) and the first
