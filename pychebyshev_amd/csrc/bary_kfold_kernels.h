@@ -22,12 +22,13 @@
 // k-steps instead of 2 KS2, the middle k-step holding the last two nodes of the first index (lane groups 0, 1) and the first
 // two of the second (lane groups 2, 3): its b1 factor is a per-lane select, and a lane's P b2 registers hold node
 // (4 s' + g) mod n2.  30^3: 900 matrix instructions per 32 points instead of 960.
-// No split launches: a small batch simply runs fewer waves, so a point's value never depends on its batch; the price is a
-// single query that waits for one wave's n1 KS2 MT matrix instructions (30^3: 480 = 13 us, 64^3: 4,096 = 0.11 ms).  A
-// version that finished dimension 1 in four chunks (b0 resident beside b1, chunk sums added in a fixed order, small batches
-// split over blockIdx.y) was built and measured: the larger table costs a workgroup per CU and 5-7 % of the throughput on
-// every shape (30^3 0.654 -> 0.616, 64^3 0.90 -> 0.85) -- not kept.  Four column tiles per wave (a lane per point, each fragment
-// feeding four matrix instructions; 204 VGPRs, two workgroups per CU) measured 2 % behind two on 26^3 ... 32^3 -- not kept either.
+// Small batches (SM, below): a workgroup of MT waves owns one column tile and every wave one of its row tiles -- the accumulators
+// of different row tiles never meet before the epilogue, whose FMA chain the waves then run one after the other, so the
+// arithmetic and its order are the unsplit kernel's and a point's value does not depend on its batch.  Dimension 1 is NOT split:
+// a version that finished it in four chunks (b0 resident beside b1, chunk sums added in a fixed order, small batches split over
+// blockIdx.y) was built and measured -- the larger table costs a workgroup per CU and 5-7 % of the throughput on every shape
+// (30^3 0.654 -> 0.616, 64^3 0.90 -> 0.85) -- not kept.  Four column tiles per wave (a lane per point, each fragment feeding four
+// matrix instructions; 204 VGPRs, two workgroups per CU) measured 2 % behind two on 26^3 ... 32^3 -- not kept either.
 #pragma once
 
 #include "pcx_common.h"
@@ -124,8 +125,15 @@ __host__ __device__ constexpr int kfold_depth(int fr) {
 
 // 256 threads = 4 waves walking the fragment image in step (L1 sharing, as k_bary_mfma_grid), PW = 16 NT points per wave;
 // dynamic LDS = 4 * kp.trows * PW * 8 bytes.  grid = (point blocks, 1, specs).
-template <int MT, int KS2, int NT, bool STR>
-__global__ void __launch_bounds__(256, 2)      // STR holds 2 KS2 - 1 b2 registers per column tile: keep three waves per SIMD
+// SM ("split M", small batches): a workgroup of MT waves owns ONE column tile and every wave ONE of its row tiles, so a
+// single query waits for n1 KS2 matrix instructions instead of n1 KS2 MT; the waves then run the epilogue's FMA chain one after
+// the other (wave t continues from wave t - 1's value through LDS): the arithmetic of the unsplit kernel in its order, so
+// a point's value still does not depend on its batch.  Host call with one point, unsplit -> split (grid form): 64^3 171 -> 106
+// (89) us, 48^3 95 -> 78 (72) us; 4,096 points: 64^3 167 -> 103 (119) us.
+template <int MT, int KS2, int NT, bool STR, bool SM = false>
+// STR holds 2 KS2 - 1 b2 registers per column tile: n2 = 22, 26 fit three waves per SIMD (168 VGPRs; same box: 26^3 0.565 -> 0.585),
+// n2 = 30 would spill 18 registers there (0.667 -> 0.650) and stays at two.
+__global__ void __launch_bounds__(SM ? 64 * MT : 256, (STR && MT <= 2 && KS2 <= 7) ? 3 : 2)
 k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ nodes, const double *__restrict__ wts,
                   const double *__restrict__ snodes, const double *const *__restrict__ frag_tab,
                   const double *__restrict__ pts, double *__restrict__ out, long N, long ostride, long ooff,
@@ -134,8 +142,11 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
     extern __shared__ double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
-    double *bw = lds + (size_t)wave * kp.trows * PW;
-    const long base = ((long)blockIdx.x * 4 + wave) * PW;
+    static_assert(!SM || (NT == 1 && MT >= 2), "split-M launches: one column tile per workgroup, one row tile per wave");
+    constexpr int MTL = SM ? 1 : MT;                    // row tiles this wave accumulates
+    const int t0 = SM ? wave : 0;                       // ... starting at this one
+    double *bw = lds + (size_t)wave * kp.trows * PW;     // (SM: every wave forms its own copy of the table)
+    const long base = SM ? (long)blockIdx.x * PW : ((long)blockIdx.x * 4 + wave) * PW;
     typedef const double __attribute__((address_space(1))) *gptr_t;
     const gptr_t tf = (gptr_t)frag_tab[blockIdx.z] + lane;
     // two lanes form the weights of one point, half the nodes each (NT = 1: lanes 32 .. 63 idle through it); one dimension
@@ -184,19 +195,24 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
 #pragma unroll
         for (int s = 0; s < P; ++s) B2[nt][s] *= rp;
     }
-    pcx_d4 acc[MT][NT];
+    pcx_d4 acc[MTL][NT];
 #pragma unroll
-    for (int t = 0; t < MT; ++t)
+    for (int t = 0; t < MTL; ++t)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[t][nt] = (pcx_d4){0.0, 0.0, 0.0, 0.0};
     // a ring of DEPTH fragments runs ahead of the multiplication: the register a k-step has read is refilled at once with
     // the fragment DEPTH positions on (the image carries PCX_KFOLD_PAD fragments behind its end for the last refills)
-    constexpr int FR = P * MT;
-    constexpr int DEPTH = kfold_depth(FR);
+    constexpr int FR = P * MT;                           // fragments per body in the image
+    constexpr int FRL = P * MTL;                         // ... of them this wave's (SM: every MT-th)
+    constexpr int DEPTH = kfold_depth(FRL);
     static_assert(DEPTH <= PCX_KFOLD_PAD, "ring deeper than the image's pad");
+    // position i of this wave's fragment sequence -> index in the image (SM: the fragments of row tile t0 only)
+    // (there the look-ahead is clamped to the last body: DEPTH positions of ONE tile's sequence are DEPTH MT fragments of the image)
+    const size_t lastpos = (size_t)kp.nbody * P - 1;
+    auto frag_at = [&](size_t i) -> size_t { return SM ? (i < lastpos ? i : lastpos) * MT + t0 : i; };
     double ring[DEPTH];
 #pragma unroll
-    for (int i = 0; i < DEPTH; ++i) ring[i] = tf[(size_t)i * 64];
+    for (int i = 0; i < DEPTH; ++i) ring[i] = tf[frag_at(i) * 64];
     constexpr int NW = STR ? 2 : 1;                      // b1 rows per body
     double w1c[NW][NT];
 #pragma unroll
@@ -205,7 +221,7 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
         for (int nt = 0; nt < NT; ++nt) w1c[w][nt] = bw[(size_t)w * PW + 16 * nt + c];
     for (int body = 0; body < kp.nbody; ++body) {
         const int bn = body + 1 < kp.nbody ? body + 1 : body;
-        const gptr_t tn = tf + ((size_t)body * FR + DEPTH) * 64;
+        const size_t nxt = (size_t)body * FRL + DEPTH;     // this wave's sequence position DEPTH ahead of the body's first
         double w1n[NW][NT];
 #pragma unroll
         for (int w = 0; w < NW; ++w)
@@ -224,13 +240,13 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
                 b[nt] = B2[nt][s] * w1;
             }
 #pragma unroll
-            for (int t = 0; t < MT; ++t) {
-                const int q = s * MT + t;
+            for (int t = 0; t < MTL; ++t) {
+                const int q = s * MTL + t;
                 const double a = ring[q % DEPTH];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) acc[t][nt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[nt], acc[t][nt], 0, 0, 0);
-                ring[q % DEPTH] = tn[(size_t)q * 64];
+                ring[q % DEPTH] = tf[frag_at(nxt + q) * 64];
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -242,20 +258,41 @@ k_bary_mfma_kfold(BaryDims dims, BaryKfoldPlan kp, const double *__restrict__ no
     __syncthreads();
     // ---- b0 -> table, epilogue: rows (g + 4 j) of every tile, then the four lane groups, times 1 / sum of dimension 0 ----
     const double r0 = weights_of(0, 0, 16 * MT);
+    double v[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) v[nt] = 0.0;
+    if constexpr (SM) {
+        // the chain v = fma(acc[t][j], b0[16 t + g + 4 j], v) runs over t in order: wave t takes over from wave t - 1
+        double *hand = lds + (size_t)MT * kp.trows * PW;           // 64 doubles behind the tables
+        for (int t = 0; t < MT; ++t) {
+            if (wave == t) {
+                if (t > 0) v[0] = hand[lane];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[0] = __builtin_fma(acc[0][0][j], bw[(size_t)(16 * t + g + 4 * j) * PW + c], v[0]);
+                hand[lane] = v[0];
+            }
+            __syncthreads();
+        }
+        if (wave != MT - 1) return;
+    } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[nt] = __builtin_fma(acc[t][nt][j], bw[(size_t)(16 * t + g + 4 * j) * PW + 16 * nt + c], v[nt]);
+    }
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const double rp = __shfl(r0, 16 * nt + c, 64);
-        double v = 0.0;
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v = __builtin_fma(acc[t][nt][j], bw[(size_t)(16 * t + g + 4 * j) * PW + 16 * nt + c], v);
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
+        double y = v[nt];
+        y += __shfl_xor(y, 16, 64);
+        y += __shfl_xor(y, 32, 64);
         const long pidx = base + 16 * nt + c;
         if (g == 0 && pidx < N) {
             const long row = perm ? (long)perm[pidx] : pidx;
-            out[row * ostride + ooff + blockIdx.z] = v * rp;
+            out[row * ostride + ooff + blockIdx.z] = y * rp;
         }
     }
 }

@@ -78,6 +78,21 @@ static int launch_kfold_t(pcx_bary *h, const double *const *frag_tab, int m, con
     if constexpr (MT * KS2 < 8 || (STR && (KS2 < 6 || KS2 > 8))) {
         return fail(PCX_ERR_UNSUPPORTED, "no k-fold MFMA instantiation for MT=%d KS2=%d", MT, KS2);
     } else {
+        // small batches: one row tile per wave (split-M launch) while that still leaves CUs idle -- a wave's chain of matrix
+        // instructions is what a single query waits for
+        if constexpr (NT == 1 && MT >= 2) {
+            const long tiles = (N + 15) / 16;
+            if (tiles * m <= 1024) {
+                const size_t lds = (size_t)MT * h->kf.trows * 16 * sizeof(double) + 64 * sizeof(double);
+                auto kern = k_bary_mfma_kfold<MT, KS2, 1, STR, true>;
+                if (lds > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(kern, dim3((unsigned)tiles, 1, (unsigned)m), dim3(64 * MT), lds, st, h->dims, h->kf, h->d_nodes,
+                                   h->d_wts, h->grid_prod ? h->d_gsnodes : nullptr, frag_tab, d_pts, d_out, N, ostride, ooff, perm);
+                HIP_TRY(hipGetLastError());
+                return PCX_OK;
+            }
+        }
         const size_t lds = bary_kfold_lds_bytes(h->kf, NT);
         auto kern = k_bary_mfma_kfold<MT, KS2, NT, STR>;
         if (lds > 64 * 1024)
