@@ -130,6 +130,9 @@ int pcx_bary_eval_multi_batch(pcx_bary *h, const double *pts, int64_t N, const i
  * arrays for the call (arrays the caller has page-locked itself -- pcx_host_register -- are taken as they are);
  * with pin = 0 and pageable arrays, or when the registration fails, the whole batch goes through handles[0]
  * (several host threads never copy to or from one pageable allocation; PCX_FANOUT_LOG=1 reports the fallback).
+ * Prefer pin = 0 over arrays registered ONCE (pcx_host_register, for the arrays' lifetime): a heap range registered and
+ * released per call has ended later calls over the same addresses in a GPU memory access fault; the
+ * Python layer passes pin = 0 unless asked (to_device(devices=..., pin=True)).
  * Replaces the reference's single-process vectorized_eval_batch (barycentric.py:992) when the process sees more
  * than one GPU.                                                                                              */
 int pcx_bary_group_eval_multi_batch(pcx_bary *const *handles, int n_handles, const double *pts, int64_t N,

@@ -408,7 +408,7 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
             print(f"  Built in {self.build_time:.3f}s ({total_weights} weights, {total_weights * 8} bytes)")
 
     # ---------------------------------------------------------------- device plumbing
-    def to_device(self, device: int | None = None, *, devices=None, pin: bool = True) -> "ChebyshevApproximation":
+    def to_device(self, device: int | None = None, *, devices=None, pin: bool = False) -> "ChebyshevApproximation":
         """Upload (or re-upload) the model to GPU ``device`` (default: ``PCX_DEVICE`` /
         ``LOCAL_RANK`` / 0).  Called lazily by the first evaluation.
 
@@ -435,9 +435,11 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         self._device_model = _DeviceModel(self, dev)
         self._fanout = [self._device_model] + [_DeviceModel(self, g) for g in (devices or [])[1:]]
         self._fanout_devices = list(devices) if devices else None
-        # fan-out only: page-lock the caller's arrays for the duration of each call (hipHostRegister over the points and the
-        # result: copies at PCIe rate, at the price of a registration per call); pin=False fans out only over arrays the
-        # caller page-locked itself (pcx_host_register) and sends everything else through the first device
+        # fan-out only.  pin=False (default since round 4): fan out over arrays the caller page-locked itself (pcx_host_register,
+        # held for the arrays' lifetime) and send everything else through the first device.  pin=True: page-lock the caller's
+        # arrays for the duration of each call (hipHostRegister over the points and the result, released afterwards) -- copies
+        # at PCIe rate, but a heap range that was registered and released has three times ended a LATER call over the same
+        # addresses in a GPU memory access fault (tools/soak.py --pin): opt-in, for processes that keep their arrays
         self._fanout_pin = bool(pin)
         return self
 
@@ -467,7 +469,7 @@ class ChebyshevApproximation(ErgonomicsMixin, DerivativeIdMixin):
         harr, keep = _lib.handle_array([g.handle for g in models])
         _lib.check(m0.lib.pcx_bary_group_eval_multi_batch(harr, len(models), _lib.p_f64(pts), pts.shape[0],
                                                           _lib.p_i32(specs), k, _lib.p_f64(out),
-                                                          1 if getattr(self, "_fanout_pin", True) else 0), m0.lib)
+                                                          1 if getattr(self, "_fanout_pin", False) else 0), m0.lib)
 
     def _model(self) -> _DeviceModel:
         """The device copy for ``_device_index`` (default device when unset); rebuilt when

@@ -227,8 +227,11 @@ struct HostPin {
         return false;
     }
     ~HostPin() {
-        if (a) (void)hipHostUnregister(a);
-        if (b) (void)hipHostUnregister(b);
+        for (void *p : {a, b})
+            if (p && hipHostUnregister(p) != hipSuccess) {
+                (void)hipGetLastError();
+                fprintf(stderr, "libpcx_hip: hipHostUnregister(%p) failed -- the range stays page-locked\n", p);
+            }
     }
 };
 

@@ -925,6 +925,9 @@ def test_near_node_points_through_the_lane_per_point_kernels(oracle_mod, shape, 
     assert np.array_equal(c.vectorized_eval_batch(grid, [0] * d), T[tuple(idx.T)])
 
 
+_PAGE_LOCKED_FOR_GOOD = []        # arrays registered with pcx_host_register and kept alive (and registered) until the process ends
+
+
 def test_single_process_fan_out_over_device_handles(bs5d):
     """one process, several device handles -- contiguous row blocks, one host thread per handle, every
     download into its slice of the caller's array (pcx_bary_group_eval_multi_batch).  One GPU here: device 0 listed
@@ -943,8 +946,19 @@ def test_single_process_fan_out_over_device_handles(bs5d):
         assert np.array_equal(fan.vectorized_eval_multi_batch(pts, specs), m1)
         assert np.array_equal(fan.vectorized_eval_batch(pts[:5000], [2, 0, 0, 0, 0]), one.vectorized_eval_batch(pts[:5000], [2, 0, 0, 0, 0]))
         assert fan.vectorized_eval(list(pts[3]), [0] * 5) == y1[3]
-    # the C ABI refuses a group of different models and reports a failing block with its index
+    # the concurrent path proper, over arrays page-locked ONCE and for good (pcx_host_register, never released in this process:
+    # per-call registration is what DESIGN 7 retired): two handles, pin = 0, through the C ABI
     m = one._model()
+    pl_pts, pl_out = np.ascontiguousarray(pts), np.empty(N)
+    _PAGE_LOCKED_FOR_GOOD.extend([pl_pts, pl_out])
+    assert m.lib.pcx_host_register(m.device, pl_pts.ctypes.data_as(ctypes.c_void_p), pl_pts.nbytes) == 0
+    assert m.lib.pcx_host_register(m.device, pl_out.ctypes.data_as(ctypes.c_void_p), pl_out.nbytes) == 0
+    two = ChebyshevApproximation.from_values(g["tensor"], 5, F.BS5_DOMAIN, F.BS5_NODES).to_device(devices=[0, 0])
+    harr2, keep2 = _lib.handle_array([gm.handle for gm in two._fanout])
+    assert m.lib.pcx_bary_group_eval_multi_batch(harr2, 2, _lib.p_f64(pl_pts), N, _lib.p_i32(_lib.i32([0] * 5)), 1,
+                                                 _lib.p_f64(pl_out), 0) == 0
+    assert np.array_equal(pl_out, y1)
+    # the C ABI refuses a group of different models and reports a failing block with its index
     other = ChebyshevApproximation.from_values(np.ones((3, 3)), 2, [[0, 1], [0, 1]], [3, 3]).to_device(0)._model()
     harr, keep = _lib.handle_array([m.handle, other.handle])
     out = np.empty(N)
@@ -957,7 +971,8 @@ def test_fan_out_with_result_arrays_that_grow_between_calls(bs5d):
     previous call's (2^18 -> 2^19 rows: NumPy grows the block in place on the heap, and the caller's arrays are registered
     for each call; tools/soak.py --pin found it).  The sequence that did it, against the single-handle results; since the fix
     the arrays are checked (and taken as they are when the caller has page-locked them) before they are registered, and a
-    batch whose arrays cannot be page-locked goes through one handle."""
+    batch whose arrays cannot be page-locked goes through one handle.  (Since the end of round 4 per-call registration is opt-in,
+    pin=True: with the default these batches of pageable arrays take the one-handle path the last sentence describes.)"""
     c, g = bs5d
     rng = np.random.default_rng(5)
     big = np.column_stack([rng.uniform(lo, hi, 1 << 20) for lo, hi in F.BS5_DOMAIN])
