@@ -67,6 +67,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+# Host arrays this process page-locked with pcx_host_register stay registered -- and alive -- until it exits: a heap range
+# that was registered and RELEASED has ended later calls over the same addresses in a GPU memory access fault
+# (tools/soak.py --pin), and the legs that follow a page-locked leg here copy to and from fresh NumPy arrays.
+_LOCKED_UNTIL_EXIT = []
+
 FP64_MFMA_PEAK_TFLOPS = 78.6      # MI355X FP64 matrix peak (= FP64 vector peak), AMD spec;
                                   # v_mfma_f64_16x16x4_f64 at 64 cycles/SIMD x 1024 SIMDs x 2.4 GHz
 HBM_PEAK_GBS = 8000.0
@@ -659,7 +664,7 @@ def run_rank(args) -> int:
         if shared is not None:
             shared.close()
         if pts_locked:
-            lib.pcx_host_unregister(pts.ctypes.data_as(ctypes.c_void_p))
+            _LOCKED_UNTIL_EXIT.append(pts)      # stays registered (see _LOCKED_UNTIL_EXIT)
         for p in d_ptss + d_outs + d_full:
             lib.pcx_dev_free(dev, p)
         free_events()
@@ -766,8 +771,7 @@ def run_rank(args) -> int:
                     out["page_locked"] = {"value": len(pts) * wl.evals_per_point / dtp, "ms_per_call": dtp * 1e3,
                                           "pcie_gb_per_s": moved / dtp / 1e9, "register_ms_not_timed": t_reg * 1e3,
                                           "what": "the same call on caller arrays page-locked once with pcx_host_register"}
-                for a in regs:
-                    lib.pcx_host_unregister(a.ctypes.data_as(ctypes.c_void_p))
+                _LOCKED_UNTIL_EXIT.extend(regs)     # stay registered (see _LOCKED_UNTIL_EXIT)
             except Exception as exc:                                 # noqa: BLE001
                 out["page_locked"] = {"error": f"{type(exc).__name__}: {exc}"}
         return out
