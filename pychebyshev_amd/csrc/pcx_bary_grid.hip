@@ -126,7 +126,8 @@ static int launch_grid_nt(pcx_bary *h, const double *const *frag_tab, int m, con
 
 PCX_HIDDEN int bary_launch_grid(pcx_bary *h, const double *const *frag_tab, int m, const double *d_pts, long N, double *d_out,
                                 long ostride, long ooff, hipStream_t st, Scratch *split_scratch, const int *perm) {
-    // two column tiles per wave for throughput; one when the batch cannot fill the chip
+    // two column tiles per wave for throughput; one when the batch cannot fill the chip.  (Four, for plans of up to 8 k-steps,
+    // were measured in round 4: 20^3 0.487 -> 0.323, 23^3 0.500 -> 0.432, 24^3 0.559 -> 0.484, 25^3 0.425 -> 0.468 -- not kept.)
     const int nt = (N >= 65536) ? h->nt : 1;
     return nt == 2 ? launch_grid_nt<2>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm)
                    : launch_grid_nt<1>(h, frag_tab, m, d_pts, N, d_out, ostride, ooff, st, split_scratch, perm);
