@@ -186,8 +186,8 @@ int pcx_bary_kernel_info(pcx_bary *h, int32_t *info_out /* 6 ints */);
  * head dimensions instead of taking 16 consecutive rows, so the head weights need no row codes (k_bary_mfma_grid).
  * info_out: {1 when the handle's MFMA plan is of that kind else 0, rows of the first tiled dimension per tile (1, 2, 4),
  * row tiles, chunks}.  PCX_BARY_GRID=0 in the environment keeps every handle on the row-code form.
- * 3-D tensors one of whose dimensions fills whole row tiles (26 .. 32, 44 .. 48, 59 .. 64 nodes; at least 85 % of the padded
- * M x K products used, 75 % with one or two row tiles) keep that dimension in the accumulators and fold the other two into K
+ * 3-D tensors one of whose dimensions fills row tiles well (25 .. 32, 44 .. 48, 59 .. 64 nodes, or whatever prices ahead of the
+ * grid plan by the measured rule of DESIGN.md 3.1f) keep that dimension in the accumulators and fold the other two into K
  * with the B operand formed per k-step (k_bary_mfma_kfold): info_out = {2, 0, row tiles, k-steps per index of the loop
  * dimension}.  PCX_BARY_KFOLD=0 switches
  * that form off. */

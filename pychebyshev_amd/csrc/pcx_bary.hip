@@ -353,13 +353,33 @@ extern "C" int pcx_bary_create(int device, int d, const int32_t *n_nodes, const 
         // 3-D tensors one of whose dimensions fills whole row tiles: the k-fold form (bary_kfold_kernels.h) ahead of the grid
         // form -- and of the dim-0 groups: 9 x 48 x 30 runs at 0.30 of the peak on the row-code form a group would share, the
         // k-fold form (rows = the 48) takes every launch of it to 0.8
-        h->kfold_ok = bary_plan_kfold(h->dims, h->kf);
+        long kfold_est = 0;                               // permille of the FP64 peak expected of the k-fold plan
+        {
+            const long keff = bary_plan_kfold(h->dims, h->kf);
+            kfold_est = bary_kfold_estimate(h->kf, keff);
+            long geff = 0;
+            BaryGridPlan gtry;
+            gtry.MT = 0;
+            if (keff > 0 && !h->g0_ok) {
+                // the alternative is the grid form -- or the row-code form where the grid planner declines, which it does when it
+                // expects no more of its own form: priced as a grid plan either way (25 x 25 x 40: row codes 0.44, k-fold 0.6)
+                (void)bary_plan_grid(h->dims, h->plan, gtry);
+                if (gtry.MT > 0)
+                    geff = (long)((double)h->plan.M * h->plan.K * 10000.0 / ((double)gtry.MT * 16.0 * h->plan.KS * 4.0));
+            }
+            h->kfold_ok = bary_kfold_take(h->kf, keff, geff, h->plan.KS);
+        }
         if (h->kfold_ok) {
             const int nt_rc = h->nt;
             h->nt = 2;
             if (bary_kfold_lds_bytes(h->kf, 2) > (size_t)72 * 1024) h->nt = 1;      // two workgroups per CU
             if (bary_kfold_lds_bytes(h->kf, h->nt) > (size_t)150 * 1024) { h->kfold_ok = false; h->nt = nt_rc; }   // a very long middle dimension
         }
+        // where the k-fold form is taken it is also ahead of the lane-per-point kernels (round 4, k-fold / k_bary_sq in fractions of
+        // the FP64 peak: 45 x 20 x 20 0.68 / 0.31, 30 x 20 x 20 0.65 / 0.42, 32 x 16 x 16 0.65 / 0.41, 64 x 8 x 8 0.45 / 0.21, 24 x 20 x 20
+        // 0.53 / 0.46, 22^3 0.49 / 0.46; without it -- 40 x 12 x 12, 26 x 14 x 14, 21^3 -- they keep their rule)
+        // -- for tensors of 4,096 elements or more and plans expected at half the peak or better: (2, 17, 17) stays where it was
+        if (h->kfold_ok && total >= kSmallTensorElems && kfold_est >= 500) h->sq_preferred = h->small_preferred = false;
         if (h->kfold_ok && h->g0_ok) {
             h->g0_ok = false;
             (void)hipFree(h->d_rowcode_g0);

@@ -97,7 +97,9 @@ static const int kMaxSpecs = 64;      // derivative specs evaluated by one launc
 PCX_HIDDEN bool bary_plan_grid(const BaryDims &dm, const BaryMfmaPlan &plan, BaryGridPlan &gp);
 PCX_HIDDEN int bary_pack_grid(pcx_bary *h, const double *plain, double *frag);
 PCX_HIDDEN size_t bary_grid_lds_bytes(const pcx_bary *h, int nt);
-PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp);
+PCX_HIDDEN long bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp);
+PCX_HIDDEN long bary_kfold_estimate(const BaryKfoldPlan &kp, long eff);
+PCX_HIDDEN bool bary_kfold_take(const BaryKfoldPlan &kp, long eff, long grid_eff, int grid_ks);
 PCX_HIDDEN size_t bary_kfold_frag_count(const BaryKfoldPlan &kp);
 PCX_HIDDEN size_t bary_kfold_lds_bytes(const BaryKfoldPlan &kp, int nt);
 PCX_HIDDEN int bary_pack_kfold(pcx_bary *h, const double *plain, double *frag);

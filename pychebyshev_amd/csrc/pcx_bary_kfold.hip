@@ -1,18 +1,15 @@
 // pcx_bary_kfold.hip -- planning, packing and launching of k_bary_mfma_kfold (bary_kfold_kernels.h): the MFMA form for
-// 3-D tensors whose first dimension fills whole row tiles.  Part of the barycentric handle (pcx_bary.hip).
+// 3-D tensors one of whose dimensions fills row tiles well.  Part of the barycentric handle (pcx_bary.hip).
 
 #include "pcx_bary_internal.h"
 #include "bary_kfold_kernels.h"
 
-// Eligible: three dimensions -- any of them may play the rows, see kfold_try --, n0 <= 64 (four row tiles in the accumulators), n2 <= 64 (sixteen B operands of dimension 2 in
-// registers), at least 8 fragments per i1 (the prefetch ring), and little padding: the share n0 / (16 MT) x n2 / (4 KS2) of
-// real products must be at least 0.85 (30^3: 0.88, 32^3 / 48^3 / 64^3: 1.0) -- above 0.75 for one or two row tiles, where
-// the grid form's short tiles cost more than the padding: measured with PCX_BARY_KFOLD_EFF=50 against the shipped rule
-// (profiles/r04_bary_rate_probe_kfold50.txt) 26^3 0.556 / 0.472 (grid), 29^3 0.615 / 0.498, 24^3 0.552 / 0.556, 23^3 0.497 / 0.493,
-// 20^3 0.444 / 0.484, 36^3 0.614 / 0.649, 40^3 0.676 / 0.691, 52^3 0.724 / 0.767.  PCX_BARY_KFOLD=0 switches the form off,
-// PCX_BARY_KFOLD_EFF=<percent> replaces both bars (experiments).
+// Eligible (kfold_try): three dimensions -- any of them may play the rows --, n0 <= 64 (four row tiles in the accumulators),
+// n2 <= 64 (sixteen B operands of dimension 2 in registers), at least 8 fragments per i1 (the prefetch ring).  Whether an
+// eligible plan is TAKEN is decided by bary_kfold_take below (priced against the grid plan; fixed bars otherwise).
+// PCX_BARY_KFOLD=0 switches the form off, PCX_BARY_KFOLD_EFF=<percent> replaces the pricing by one bar (experiments).
 // One assignment of the three tensor dimensions to the roles (rows, loop, b2 registers): fills kp, returns the share of real
-// products in percent (0: not eligible).
+// products in hundredths of a percent (0: not eligible).
 static long kfold_try(const BaryDims &dm, int dr, int da, int db, bool straddle, BaryKfoldPlan &kp) {
     kp.dim[0] = dr; kp.dim[1] = da; kp.dim[2] = db;
     const long st[3] = {(long)dm.n[1] * dm.n[2], (long)dm.n[2], 1L};
@@ -37,12 +34,12 @@ static long kfold_try(const BaryDims &dm, int dr, int da, int db, bool straddle,
 // choosing between assignments of equal padding (20 x 16 x 64: 64 rows in four tiles, not 16 rows in one).
 static long kfold_tile_weight(int MT) { return MT >= 4 ? 100 : (MT == 3 ? 93 : (MT == 2 ? 83 : 72)); }
 
-PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp) {
-    const char *env = getenv("PCX_BARY_KFOLD"), *eff = getenv("PCX_BARY_KFOLD_EFF");    // read per handle
+// The best assignment of the roles: fills kp and returns the share of real products in hundredths of a percent (0: the form is
+// switched off or no assignment is eligible).  Whether the form is TAKEN is the caller's decision (bary_kfold_take).
+PCX_HIDDEN long bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp) {
+    const char *env = getenv("PCX_BARY_KFOLD");                                        // read per handle
     const char *strd = getenv("PCX_BARY_KFOLD_STRADDLE");                              // =0: pad n2 = 26, 30 instead (A/B)
-    int bar = eff ? atoi(eff) : 0;
-    if (bar <= 0 || bar > 100) bar = 0;
-    if ((env && env[0] == '0') || dm.d != 3) return false;
+    if ((env && env[0] == '0') || dm.d != 3) return 0;
     // the roles go to the assignment with the least padding; the natural order (rows = dimension 0, b2 = the contiguous last
     // dimension) wins ties, so cubes are packed and summed as before
     static const int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
@@ -52,9 +49,37 @@ PCX_HIDDEN bool bary_plan_kfold(const BaryDims &dm, BaryKfoldPlan &kp) {
         const long sc = kfold_try(dm, pm[0], pm[1], pm[2], !(strd && strd[0] == '0'), cand);
         if (sc * kfold_tile_weight(cand.MT) > best_w) { best_w = sc * kfold_tile_weight(cand.MT); best = sc; kp = cand; }
     }
-    if (!best) return false;
-    if (bar) return best >= bar * 100L;
-    return kp.MT <= 2 ? best > 7500 : best >= 8500;
+    return best;
+}
+
+// Take the k-fold form?  eff: bary_plan_kfold's share of real products (1e-4).  grid_eff > 0: the grid form is the alternative, with
+// that share of real products over its padded tiles and grid_ks k-steps per tile -- then both are priced by what the matrix pipe was
+// measured to make of them (fraction of the FP64 peak at full tiles: k-fold by row tiles 0.65 / 0.745 / 0.84 / 0.91 -- 15 x 33 x 31,
+// 32^3, 48^3, 64^3 --, grid by k-steps per tile 0.49 (5), 0.56, 0.58, 0.64, 0.67, 0.71 (10), 0.745, 0.78 (12), 0.84 (16) -- 20^3,
+// 24^3, 28^3, 32^3, 40^3, 48^3, 64^4) and the k-fold form must be 8 % ahead (23^3, 24^3 are level: they stay); the estimates
+// reproduce the measured pairs of profiles/r04_bary_rate_probe_kfold50.txt (26^3 0.605 / 0.465, 29^3 0.61 / 0.48, 40^3 0.70 / 0.71,
+// 52^3 0.74 / 0.77, 36^3 0.63 / 0.65) and send 25^3 (0.52 / 0.41) to the k-fold form.  No grid plan (dim-0 groups or a row-code
+// plan instead): the fixed bars, 85 % of the padded products real, more than 75 % with one or two row tiles.
+// PCX_BARY_KFOLD_EFF=<percent> replaces all of it by one bar (experiments).
+static const int kKfoldTileFrac[5] = {0, 650, 745, 840, 910};       // permille of the FP64 peak at full tiles, by row tiles
+
+// the fraction of the FP64 peak (permille) expected of the plan: share of real products x the row-tile figure above
+PCX_HIDDEN long bary_kfold_estimate(const BaryKfoldPlan &kp, long eff) {
+    return eff <= 0 ? 0 : eff * kKfoldTileFrac[kp.MT < 4 ? kp.MT : 4] / 10000;
+}
+
+PCX_HIDDEN bool bary_kfold_take(const BaryKfoldPlan &kp, long eff, long grid_eff, int grid_ks) {
+    if (eff <= 0) return false;
+    const char *e = getenv("PCX_BARY_KFOLD_EFF");
+    const int bar = e ? atoi(e) : 0;
+    if (bar > 0 && bar <= 100) return eff >= bar * 100L;
+    if (grid_eff > 0) {
+        static const int g_ks[18] = {400, 400, 400, 420, 450, 487, 560, 580, 640, 670, 710, 745, 780, 800, 815, 830, 840, 850};
+        const long est_k = eff * kKfoldTileFrac[kp.MT < 4 ? kp.MT : 4];
+        const long est_g = grid_eff * g_ks[grid_ks < 17 ? grid_ks : 17];
+        return est_k * 100 > est_g * 108;
+    }
+    return kp.MT <= 2 ? eff > 7500 : eff >= 8500;
 }
 
 PCX_HIDDEN size_t bary_kfold_frag_count(const BaryKfoldPlan &kp) {

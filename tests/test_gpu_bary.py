@@ -1043,8 +1043,10 @@ def _grid_info(c):
 
 @pytest.mark.parametrize("shape,dom,kind", [
     ((21, 21, 21), [[0, 1], [-1, 1], [2, 5]], 1),               # RA = 2: 11 x 3 tiles, 6 k-steps
-    ((17, 19, 23), [[0, 1], [-1, 1], [2, 5]], 1),               # unequal node counts, both tiled dimensions padded
+    ((17, 19, 23), [[0, 1], [-1, 1], [2, 5]], 2),               # unequal node counts: k-fold with 23 as rows priced ahead of a grid plan that pads both tiled dimensions (0.455 / 0.423)
+    ((19, 27, 35), [[0, 1], [-1, 1], [2, 5]], 1),               # ... and a shape where the grid plan is priced ahead
     ((40, 40, 40), [[-1, 1]] * 3, 1),                           # no padding at all: 100 tiles of 10 k-steps
+    ((25, 25, 25), [[-1, 1]] * 3, 2),                           # k-fold at 70 % real products: the grid plan pads more (0.52 / 0.43)
     ((65, 65, 65), [[0, 2]] * 3, 1),                            # 17 k-steps, 9 % more tiles, four-wave workgroups, A formed per chunk
     ((7, 7, 7, 7, 7), [[0, 1]] * 5, 0),                         # 13 k-steps and 27 % more tiles: stays on the row-code kernel
     ((20, 16, 64), [[0, 2]] * 3, 2),                            # k-fold with the LAST dimension as rows (64 = four whole tiles)
