@@ -1061,6 +1061,7 @@ def _grid_info(c):
     # k-fold plans (k_bary_mfma_kfold): dimension 0 in the accumulators, dimensions 1 x 2 folded into K
     ((30, 30, 30), [[-1, 1]] * 3, 2),                           # 2 row tiles, 8 k-steps per i1, both padded (0.88 used)
     ((32, 32, 32), [[0, 1], [-1, 1], [2, 5]], 2),               # nothing padded
+    ((48, 48, 48), [[0, 1]] * 3, 2),                            # three row tiles against a grid plan of 12 k-steps: priced 0.84 / 0.78, measured 0.885 / 0.805
     ((31, 70, 30), [[0, 1]] * 3, 2),                            # 70 > 64 nodes in the middle: weights by division
     ((48, 20, 47), [[0, 2]] * 3, 2),                            # 3 row tiles, 12 k-steps per i1 (ring of 12)
     ((64, 9, 64), [[0, 1]] * 3, 2),                             # 4 row tiles, 16 k-steps per i1 (ring of 16)
